@@ -1,0 +1,187 @@
+/*
+ * yume_hip.h — C-ABI of libyume_hip.so: the MI355X (gfx950) kernels behind YUME's
+ * denoise hot path (WanModel DiT block stack + causal 3D VAE).
+ *
+ * The reference has no FFI of its own for this path: it is Python calling torch ops and
+ * one external native library (flash-attn).  Each entry point below therefore names the
+ * reference Python call site(s) it replaces (paths relative to the reference root).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer into memory owned by the caller (torch-allocated);
+ *     the library never allocates or frees device memory.
+ *   - shapes are element counts, strides/leading dimensions are in ELEMENTS of the buffer type.
+ *   - bf16 buffers are passed as `const void*` / `void*` (raw 16-bit brain floats).
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream). No entry point
+ *     synchronises; all work is enqueued on `stream`.
+ *   - return value: 0 on success, a negative YUME_E* code on failure; the message for the
+ *     last failure on the calling thread is returned by yume_last_error(). Nothing throws
+ *     across the ABI.
+ *   - re-entrant across processes (one process per GPU); no internal threads, no global
+ *     mutable device state.
+ */
+#ifndef YUME_HIP_H
+#define YUME_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define YUME_OK 0
+#define YUME_EINVAL (-1)   /* bad argument (shape/alignment/NULL)          */
+#define YUME_ELAUNCH (-2)  /* hipLaunchKernel / runtime error               */
+#define YUME_EUNSUP (-3)   /* combination not implemented by this build     */
+
+/* ---- library info ------------------------------------------------------------------- */
+const char* yume_last_error(void);
+/* ABI version of this header; bumped on any signature change. */
+int yume_abi_version(void);
+/* name of the gfx target the kernels were compiled for ("gfx950"). */
+const char* yume_target_arch(void);
+
+/* ---- fused LayerNorm + modulate  ---------------------------------------------------------
+ * replaces: wan23/modules/model.py:300-301,309-310 (norm1/norm2 + `*(1+scale)+shift`),
+ *           wan23/modules/model.py:140-150 (WanLayerNorm), :308 (norm3, affine),
+ *           wan23/modules/model.py:344-347 (Head norm+modulate);  same lines in wan/modules/model.py.
+ *
+ *   y[t, :] = LN(x[t, :]; eps, no affine) * (mul[row(t), :] + add_one) + add[row(t), :]
+ *   row(t) = row_idx ? row_idx[t] : 0
+ * x: fp32 [T, C] (row stride ldx).  mul/add: fp32 tables, row stride `tab_stride` elements
+ * (for the DiT `mul`=scale chunk, `add`=shift chunk of the [R,6,C] modulation table with
+ * add_one=1; for the affine norm3 `mul`=weight, `add`=bias with add_one=0).
+ * out_kind: 0 = bf16 [T, C] (ldo), 1 = fp32 [T, C] (ldo),
+ *           2 = bf16 3-way split [T, 3C]: [hi | hi | lo] where hi=bf16(y), lo=bf16(y-hi)
+ *               (feeds the fp32-accurate head GEMM, see yume_gemm_bf16).
+ * C must be a multiple of 8 and <= 8192.
+ */
+int yume_adaln_modulate(const float* x, int64_t ldx, int64_t T, int64_t C, float eps,
+                        const float* mul, const float* add, int64_t tab_stride,
+                        const int32_t* row_idx, int add_one,
+                        void* out, int64_t ldo, int out_kind, void* stream);
+
+/* ---- bf16 MFMA GEMM with fused epilogues ------------------------------------------------
+ * replaces: every nn.Linear on the path — wan23/modules/model.py:171-174,189-195,205-206
+ *           (q,k,v,o), :222-231 (cross q,k,v,o), :265-267,309-312 (ffn + gate/residual),
+ *           :303-304 (gate + residual), :455-457,815-821 (text_embedding),
+ *           :453-454,602-720 (patch embeddings as GEMM over gathered patches), :331,346 (head).
+ *
+ *   acc[m, n] = sum_k A[m, k] * W[n, k]          (A bf16 [M,K] lda;  W bf16 [N,K] ldw = nn.Linear layout)
+ * K must be a multiple of 64; M, N arbitrary (> 0).
+ * epilogue `epi`:
+ *   YUME_EPI_BF16      out bf16 [M,N] (ldo)      = acc + bias
+ *   YUME_EPI_BF16_GELU out bf16 [M,N]            = gelu_tanh(acc + bias)
+ *   YUME_EPI_BF16_GELU_ERF  same with the exact erf GELU (img_emb MLPProj, wan/modules/model.py:534-537)
+ *   YUME_EPI_F32       out fp32 [M,N]            = acc + bias
+ *   YUME_EPI_RESID     out fp32 [M,N] in/out     += (acc + bias) * (gate ? gate[row(m), n] : 1)
+ *                      gate fp32 table, row stride gate_stride, row(m) = row_idx ? row_idx[m] : 0
+ *   YUME_EPI_BF16_SPLITT  columns n < n_split as YUME_EPI_BF16 into `out`;
+ *                      columns n >= n_split written TRANSPOSED as bf16 into outT[(n - n_split), m]
+ *                      (row stride ldt >= M) — the K-major V^T image the attention kernel consumes.
+ *                      n_split must be a multiple of 128.
+ * bias: fp32 [N] or NULL.
+ */
+enum {
+    YUME_EPI_BF16 = 0,
+    YUME_EPI_BF16_GELU = 1,
+    YUME_EPI_F32 = 2,
+    YUME_EPI_RESID = 3,
+    YUME_EPI_BF16_SPLITT = 4,
+    YUME_EPI_BF16_GELU_ERF = 5
+};
+int yume_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias,
+                   int64_t M, int64_t N, int64_t K, int epi,
+                   void* out, int64_t ldo,
+                   const float* gate, int64_t gate_stride, const int32_t* row_idx,
+                   void* outT, int64_t ldt, int64_t n_split,
+                   int variant, void* stream);
+
+/* ---- RMSNorm over the hidden dim (+ optional 3D RoPE), in place, bf16 -----------------------
+ * replaces: wan23/modules/model.py:121-137 (WanRMSNorm on q,k over the FULL hidden dim C),
+ *           :38-118 (rope_apply: interleaved-pair complex multiply with the per-token table).
+ *
+ * buf: bf16 [T, nparts*C] (row stride ld); part p (p < nparts) = columns [p*C, (p+1)*C):
+ *   y = x * rsqrt(mean_C(x^2) + eps) * w_p[c]        (fp32 math)
+ *   if rope: head-wise (head_dim D, pairs (2j,2j+1)):  (y0,y1) <- (y0*cos - y1*sin, y0*sin + y1*cos)
+ *            with rope = fp32 [T, D/2, 2] (cos, sin) per token, shared by all heads.
+ * w: fp32 [nparts, C].   C % 512 == 0, D == 128.
+ */
+int yume_rmsnorm_rope(void* buf, int64_t ld, int64_t T, int64_t C, int nparts,
+                      const float* w, float eps, const float* rope, int64_t D, void* stream);
+
+/* ---- exact-softmax attention forward (FlashAttention-style, head_dim 128) -----------------
+ * replaces: wan23/modules/attention.py:24-130 flash_attention() -> flash_attn_varlen_func
+ *           (external flash-attn 2.7.0.post2), call sites wan23/modules/model.py:197-202,227.
+ *
+ *   O[h, i, :] = softmax_j( scale * <Q[h,i,:], K[h,j,:]> ) V[h, j, :]     j < Lk, no mask, no dropout
+ * Q: bf16, token-major: element (i, h, d) at Q[i*ldq + h*128 + d];  K likewise (ldk).
+ * Vt: bf16 K-major ("V transposed"): element (j, h, d) at Vt[(h*128 + d)*ldvt + j], ldvt >= Lk,
+ *     ldvt % 8 == 0 (the image written by YUME_EPI_BF16_SPLITT / yume_transpose_bf16).
+ * O: bf16 token-major (ldo). accumulate != 0: O += result (the 14B image cross-attention sum,
+ *    wan/modules/model.py:379-387) using the fp32 accumulator before rounding.
+ */
+int yume_attn_fwd(const void* Q, int64_t ldq, const void* K, int64_t ldk, const void* Vt, int64_t ldvt,
+                  void* O, int64_t ldo, int64_t Lq, int64_t Lk, int64_t H, float scale,
+                  int accumulate, int variant, void* stream);
+
+/* ---- small-M fp32 linear (time embedding MLP) ---------------------------------------------
+ * replaces: wan23/modules/model.py:459-461,803-812 (time_embedding, time_projection under
+ *           autocast(float32)); only R distinct timesteps are evaluated (R <= 8).
+ *   out[r, n] = bias[n] + sum_k act(in[r, k]) * W[n, k] ;  act: 0 = identity, 1 = SiLU
+ *   out_act: 0 = none, 1 = SiLU applied to the result.
+ * W: fp32 (w_bf16 = 0) or bf16 (w_bf16 = 1), [N, K] row-major. K % 8 == 0.
+ * add_table (optional, fp32 [N]): out[r, n] += add_table[n] (folds `modulation + e0`).
+ */
+int yume_linear_smallm_f32(const float* in, int64_t R, int64_t K, const void* W, int w_bf16,
+                           const float* bias, int64_t N, int in_act, int out_act,
+                           const float* add_table, float* out, void* stream);
+
+/* ---- sinusoidal timestep embedding ---------------------------------------------------------
+ * replaces: wan23/modules/model.py:14-24 sinusoidal_embedding_1d (fp64 math, fp32 result).
+ * t: fp64 device array (the reference casts positions to float64); row r uses t[t_index[r]]
+ * (t_index: device int32 [R], or NULL for t[r]).  out fp32 [R, dim], dim even.
+ */
+int yume_sinusoidal_embed(const double* t, const int32_t* t_index, int64_t R, int64_t dim,
+                          float* out, void* stream);
+
+/* ---- modulation tables -----------------------------------------------------------------------
+ * replaces: wan23/modules/model.py:295-297 `(self.modulation.unsqueeze(0) + e).chunk(6)` for every
+ *           block at once, and :344 for the head: out[b, r, :] = tab[b, :] + e0[r, :].
+ * tab fp32 [B, W] (stacked block.modulation, W = 6*C), e0 fp32 [R, W], out fp32 [B, R, W]. W % 4 == 0.
+ */
+int yume_modulation_table(const float* tab, const float* e0, int64_t B, int64_t R, int64_t W,
+                          float* out, void* stream);
+
+/* ---- patch gather (im2col for stride==kernel Conv3d) ----------------------------------------
+ * replaces: wan23/modules/model.py:602-720 patch_embedding{,_2x,_4x,_8x,_16x}(convpadd(...)):
+ *           gathers the (1,kh,kw) patches of `nf` frames into a bf16 matrix the GEMM consumes.
+ * x: fp32 or bf16 [Cin, F, H, W] contiguous (in_bf16 selects); frames f0 .. f0+nf-1.
+ * out: bf16 [nf*Hp*Wp, Kp] with Hp = ceil(H/kh), Wp = ceil(W/kw), column order (c, dh, dw),
+ *      zero for h >= H or w >= W (convpadd :918-931) and for columns >= Cin*kh*kw (K padding to Kp).
+ */
+int yume_patch_gather(const void* x, int in_bf16, int64_t Cin, int64_t F, int64_t H, int64_t W,
+                      int64_t f0, int64_t nf, int64_t kh, int64_t kw,
+                      void* out, int64_t Kp, void* stream);
+
+/* ---- unpatchify ------------------------------------------------------------------------------
+ * replaces: wan23/modules/model.py:867-890 (einsum 'fhwpqrc->cfphqwr', patch (1,ph,pw)).
+ * in: fp32 [F*Hp*Wp, ph*pw*Cout] (ld = ldi) ; out: fp32 [Cout, F, Hp*ph, Wp*pw].
+ */
+int yume_unpatchify(const float* in, int64_t ldi, int64_t Fr, int64_t Hp, int64_t Wp,
+                    int64_t ph, int64_t pw, int64_t Cout, float* out, void* stream);
+
+/* ---- layout / dtype helpers -------------------------------------------------------------------
+ * yume_cast_bf16: fp32 [rows, cols] (ldi) -> bf16 (ldo), rows beyond `rows_valid` written as 0
+ *   (zero-padding the text context to text_len, wan23/modules/model.py:816-821).
+ * yume_transpose_bf16: in [rows, cols] (fp32 or bf16, ldi) -> out bf16 [cols, rows] (ldo); builds the
+ *   K-major V^T image for callers that enter at the flash_attention() seam with token-major v.
+ */
+int yume_cast_bf16(const float* in, int64_t ldi, int64_t rows_valid, int64_t rows, int64_t cols,
+                   void* out, int64_t ldo, void* stream);
+int yume_transpose_bf16(const void* in, int in_bf16, int64_t ldi, int64_t rows, int64_t cols,
+                        void* out, int64_t ldo, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* YUME_HIP_H */

@@ -1,0 +1,109 @@
+"""TEST INFRASTRUCTURE ONLY — imports the REAL reference modules from /root/reference.
+
+Only usable in the build container (the GPU box has no /root/reference). Used by
+oracle/make_golden.py to generate tests/golden/* and by the `-m "not gpu"` tests that pin the
+oracle restatement (oracle/dit.py, oracle/vae.py) against the reference itself.
+
+Recipe: stub the 4 diffusers symbols the model files import, import
+wan{,23}/modules/{attention,model}.py by file path under a synthetic package (the real package
+__init__ pulls torchvision/easydict/peft which are not installed), and rebind `flash_attention`
+(needs CUDA + the un-vendored flash-attn 2.7.0.post2 wheel) to an exact-softmax restatement that
+follows wan/modules/attention.py:56-130.
+"""
+import importlib.util
+import math
+import os
+import sys
+import types
+
+import torch
+import torch.nn as nn
+
+REF_ROOT = os.environ.get("YUME_REFERENCE_ROOT", "/root/reference")
+
+
+def available():
+    return os.path.isfile(os.path.join(REF_ROOT, "wan23", "modules", "model.py"))
+
+
+def _stub_diffusers():
+    if "diffusers" in sys.modules and not getattr(sys.modules["diffusers"], "_yume_stub", False):
+        return
+    d = types.ModuleType("diffusers")
+    d._yume_stub = True
+    cu = types.ModuleType("diffusers.configuration_utils")
+    cu.ConfigMixin = type("ConfigMixin", (), {})
+    cu.register_to_config = lambda f: f
+    dm = types.ModuleType("diffusers.models")
+    mu = types.ModuleType("diffusers.models.modeling_utils")
+    mu.ModelMixin = type("ModelMixin", (nn.Module,), {})
+    sys.modules.update({"diffusers": d, "diffusers.configuration_utils": cu, "diffusers.models": dm,
+                        "diffusers.models.modeling_utils": mu})
+
+
+def sdpa_standin(q, k, v, q_lens=None, k_lens=None, dropout_p=0., softmax_scale=None, q_scale=None, causal=False,
+                 window_size=(-1, -1), deterministic=False, dtype=torch.bfloat16, version=None):
+    """Exact softmax attention with flash_attention()'s signature (attention.py:24-38): q,k,v [B,L,N,D],
+    scale 1/sqrt(D), k_lens honoured by truncation, output in q.dtype. fp32 gold: no bf16 cast."""
+    assert not causal and dropout_p == 0. and q_lens is None
+    out_dtype = q.dtype
+    b = q.size(0)
+    outs = []
+    for i in range(b):
+        lk = int(k_lens[i]) if k_lens is not None else k.size(1)
+        qi = q[i].transpose(0, 1).double()
+        ki = k[i, :lk].transpose(0, 1).double()
+        vi = v[i, :lk].transpose(0, 1).double()
+        if q_scale is not None:
+            qi = qi * q_scale
+        sc = softmax_scale if softmax_scale is not None else 1.0 / math.sqrt(q.size(-1))
+        a = torch.softmax(qi @ ki.transpose(1, 2) * sc, dim=-1)
+        outs.append((a @ vi).transpose(0, 1))
+    return torch.stack(outs).to(out_dtype)
+
+
+def _import_pkg(pkg, files):
+    root = types.ModuleType(pkg)
+    root.__path__ = [os.path.join(REF_ROOT, pkg)]
+    sub = types.ModuleType(pkg + ".modules")
+    sub.__path__ = [os.path.join(REF_ROOT, pkg, "modules")]
+    sys.modules[pkg] = root
+    sys.modules[pkg + ".modules"] = sub
+    mods = {}
+    for f in files:
+        name = f"{pkg}.modules.{f}"
+        spec = importlib.util.spec_from_file_location(name, os.path.join(REF_ROOT, pkg, "modules", f + ".py"))
+        m = importlib.util.module_from_spec(spec)
+        sys.modules[name] = m
+        spec.loader.exec_module(m)
+        mods[f] = m
+    return mods
+
+
+_cache = {}
+
+
+def ref_dit(family="wan23"):
+    """Returns the reference `model` module of wan23 (5B arch) or wan (14B arch), flash_attention rebound."""
+    assert available(), "reference tree not present"
+    key = ("dit", family)
+    if key not in _cache:
+        _stub_diffusers()
+        mods = _import_pkg(family, ["attention", "model"])
+        mods["model"].flash_attention = sdpa_standin
+        _cache[key] = mods["model"]
+    return _cache[key]
+
+
+def ref_vae(which="vae2_2"):
+    """Returns the reference VAE module: 'vae2_2' (wan23/modules/vae2_2.py) or 'vae2_1' (wan/modules/vae.py)."""
+    assert available(), "reference tree not present"
+    key = ("vae", which)
+    if key not in _cache:
+        path = {"vae2_2": os.path.join(REF_ROOT, "wan23", "modules", "vae2_2.py"),
+                "vae2_1": os.path.join(REF_ROOT, "wan", "modules", "vae.py")}[which]
+        spec = importlib.util.spec_from_file_location("yume_ref_" + which, path)
+        m = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(m)
+        _cache[key] = m
+    return _cache[key]

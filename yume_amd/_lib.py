@@ -1,0 +1,59 @@
+"""ctypes binding of libyume_hip.so (the C-ABI declared in include/yume_hip.h).
+
+The product path has NO fallback: if the shared library is missing or a symbol is absent this
+module raises at import of the symbol, and every op raises RuntimeError on a non-zero return code.
+"""
+import ctypes
+import os
+from ctypes import c_void_p, c_int, c_int64, c_float, c_char_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libyume_hip.so")
+
+_P, _I, _L, _F = c_void_p, c_int, c_int64, c_float
+
+# name -> argtypes  (restype is int unless listed in _RES)
+SIGNATURES = {
+    "yume_last_error": [],
+    "yume_abi_version": [],
+    "yume_target_arch": [],
+    "yume_adaln_modulate": [_P, _L, _L, _L, _F, _P, _P, _L, _P, _I, _P, _L, _I, _P],
+    "yume_gemm_bf16": [_P, _L, _P, _L, _P, _L, _L, _L, _I, _P, _L, _P, _L, _P, _P, _L, _L, _I, _P],
+    "yume_rmsnorm_rope": [_P, _L, _L, _L, _I, _P, _F, _P, _L, _P],
+    "yume_attn_fwd": [_P, _L, _P, _L, _P, _L, _P, _L, _L, _L, _L, _F, _I, _I, _P],
+    "yume_linear_smallm_f32": [_P, _L, _L, _P, _I, _P, _L, _I, _I, _P, _P, _P],
+    "yume_sinusoidal_embed": [_P, _P, _L, _L, _P, _P],
+    "yume_modulation_table": [_P, _P, _L, _L, _L, _P, _P],
+    "yume_patch_gather": [_P, _I, _L, _L, _L, _L, _L, _L, _L, _L, _P, _L, _P],
+    "yume_unpatchify": [_P, _L, _L, _L, _L, _L, _L, _L, _P, _P],
+    "yume_cast_bf16": [_P, _L, _L, _L, _L, _P, _L, _P],
+    "yume_transpose_bf16": [_P, _I, _L, _L, _L, _P, _L, _P],
+}
+_RES = {"yume_last_error": c_char_p, "yume_target_arch": c_char_p}
+
+_lib = None
+
+
+def load():
+    """Load libyume_hip.so (once). Raises RuntimeError with a build hint if it is not there."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: the HIP extension has not been built. "
+            "Run `python -c 'import __graft_entry__ as g; g.build()'` (or `python -m yume_amd.build`). "
+            "There is no CPU/PyTorch fallback for the yume_amd hot path.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.argtypes = argtypes
+        fn.restype = _RES.get(name, c_int)
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().yume_last_error()
+        raise RuntimeError(f"{what} failed (rc={rc}): {msg.decode() if msg else '?'}")

@@ -1,0 +1,80 @@
+"""Builds libyume_hip.so (gfx950) in-tree with hipcc. No cmake, no JIT cache: the .so travels with the tree.
+
+    python -m yume_amd.build [--force]
+"""
+import hashlib
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIBDIR = os.path.join(HERE, "lib")
+LIBPATH = os.path.join(LIBDIR, "libyume_hip.so")
+INCLUDE = os.path.join(os.path.dirname(HERE), "include")
+
+ARCH = "gfx950"
+FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-ffp-contract=fast",
+         "-Wno-unused-result", "-DNDEBUG"]
+
+
+def _hipcc():
+    for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
+            return c
+    raise RuntimeError("hipcc not found")
+
+
+def sources():
+    return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
+
+
+def _fingerprint():
+    h = hashlib.sha256()
+    files = sorted([os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(INCLUDE, "yume_hip.h")])
+    for f in files:
+        if os.path.isfile(f):
+            h.update(f.encode())
+            with open(f, "rb") as fh:
+                h.update(fh.read())
+    h.update(" ".join(FLAGS).encode())
+    return h.hexdigest()
+
+
+def build_library(force=False, verbose=True):
+    """Compile every csrc/*.hip for gfx950 and link lib/libyume_hip.so. Returns the library path."""
+    os.makedirs(LIBDIR, exist_ok=True)
+    stamp = os.path.join(LIBDIR, "build.stamp")
+    fp = _fingerprint()
+    if not force and os.path.exists(LIBPATH) and os.path.exists(stamp) and open(stamp).read().strip() == fp:
+        return LIBPATH
+    hipcc = _hipcc()
+    objdir = os.path.join(LIBDIR, "obj")
+    os.makedirs(objdir, exist_ok=True)
+
+    def compile_one(src):
+        obj = os.path.join(objdir, os.path.basename(src)[:-4] + ".o")
+        cmd = [hipcc] + FLAGS + ["-I", INCLUDE, "-c", src, "-o", obj]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")
+        if verbose and r.stderr.strip():
+            sys.stderr.write(r.stderr)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
+        objs = list(ex.map(compile_one, sources()))
+    cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIBPATH] + objs
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+    with open(stamp, "w") as fh:
+        fh.write(fp)
+    if verbose:
+        print(f"[yume_amd.build] built {LIBPATH}")
+    return LIBPATH
+
+
+if __name__ == "__main__":
+    build_library(force="--force" in sys.argv)

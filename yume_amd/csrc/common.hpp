@@ -1,0 +1,77 @@
+// common.hpp — shared device/host helpers for libyume_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include "../../include/yume_hip.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(8))) unsigned short u16x8;
+typedef __attribute__((ext_vector_type(4))) unsigned short u16x4;
+typedef __attribute__((ext_vector_type(2))) unsigned short u16x2;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+
+#define WAVE 64
+
+// ---- error plumbing (host) -------------------------------------------------------------
+void yume_set_error(const char* fmt, ...);
+
+#define YUME_REQUIRE(cond, ...)                      \
+    do {                                             \
+        if (!(cond)) {                               \
+            yume_set_error(__VA_ARGS__);             \
+            return YUME_EINVAL;                      \
+        }                                            \
+    } while (0)
+
+#define YUME_CHECK_LAUNCH(name)                                                       \
+    do {                                                                              \
+        hipError_t e__ = hipGetLastError();                                           \
+        if (e__ != hipSuccess) {                                                      \
+            yume_set_error("%s: launch failed: %s", name, hipGetErrorString(e__));    \
+            return YUME_ELAUNCH;                                                      \
+        }                                                                             \
+    } while (0)
+
+// ---- bf16 <-> f32 (device) ------------------------------------------------------------
+__device__ __forceinline__ float bf16_to_f32(unsigned short h) {
+    return __uint_as_float(((unsigned int)h) << 16);
+}
+// round-to-nearest-even, NaN preserved (quiet)
+__device__ __forceinline__ unsigned short f32_to_bf16(float f) {
+    unsigned int u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+__device__ __forceinline__ unsigned int pack_bf16x2(float lo, float hi) {
+    return (unsigned int)f32_to_bf16(lo) | ((unsigned int)f32_to_bf16(hi) << 16);
+}
+
+// ---- wave / block reductions --------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// tanh-approximated GELU exactly as torch.nn.GELU(approximate='tanh'):
+//   0.5*x*(1+tanh(sqrt(2/pi)*(x+0.044715 x^3)))
+__device__ __forceinline__ float gelu_tanh(float x) {
+    const float k0 = 0.7978845608028654f, k1 = 0.044715f;
+    float u = k0 * (x + k1 * x * x * x);
+    // tanh(u) = 1 - 2/(exp(2u)+1); saturates cleanly for |u| large
+    float e = __expf(2.0f * u);
+    float t = 1.0f - 2.0f / (e + 1.0f);
+    return 0.5f * x * (1.0f + t);
+}
+__device__ __forceinline__ float silu(float x) { return x / (1.0f + __expf(-x)); }

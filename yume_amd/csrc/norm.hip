@@ -1,0 +1,213 @@
+// norm.hip — HBM-bound row kernels of the DiT block:
+//   * fused LayerNorm(no affine) + modulate -> bf16 / fp32 / 3-way bf16 split
+//   * RMSNorm over the full hidden dim (+ interleaved-pair 3D RoPE), in place on bf16 q|k
+// One 256-thread workgroup per token row; every global access is a 16-byte vector.
+// Roofline: HBM. Algorithmic bytes per token: adaln 4C read + 2C write; rmsnorm_rope 2*nparts*C r+w.
+#include "common.hpp"
+
+namespace {
+
+constexpr int NT = 256;
+
+__device__ __forceinline__ float block_sum(float v, float* red /*[8]*/) {
+    v = wave_sum(v);
+    const int wid = threadIdx.x >> 6;
+    __syncthreads();  // protect `red` against the previous use
+    if ((threadIdx.x & 63) == 0) red[wid] = v;
+    __syncthreads();
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < NT / 64; ++i) t += red[i];
+    return t;
+}
+
+// MAXV = max float4 vectors per thread (C <= NT*4*MAXV)
+template <int MAXV>
+__global__ __launch_bounds__(NT) void adaln_kernel(const float* __restrict__ x, int64_t ldx, int C, float eps,
+                                                   const float* __restrict__ mul, const float* __restrict__ add,
+                                                   int64_t tab_stride, const int32_t* __restrict__ row_idx,
+                                                   float add_one, void* __restrict__ out, int64_t ldo,
+                                                   int out_kind) {
+    __shared__ float red[8];
+    const int64_t t = blockIdx.x;
+    const float* xr = x + t * ldx;
+    const int nvec = C >> 2;
+    f32x4 v[MAXV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int vi = threadIdx.x + i * NT;
+        if (vi < nvec) {
+            v[i] = *reinterpret_cast<const f32x4*>(xr + 4 * vi);
+            s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+        } else {
+            v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+    const float mean = block_sum(s, red) / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int vi = threadIdx.x + i * NT;
+        if (vi < nvec) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float d = v[i][j] - mean;
+                q += d * d;
+            }
+        }
+    }
+    const float var = block_sum(q, red) / (float)C;
+    const float rstd = rsqrtf(var + eps);
+    const int64_t row = row_idx ? (int64_t)row_idx[t] : 0;
+    const float* mr = mul + row * tab_stride;
+    const float* ar = add + row * tab_stride;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int vi = threadIdx.x + i * NT;
+        if (vi < nvec) {
+            const f32x4 m4 = *reinterpret_cast<const f32x4*>(mr + 4 * vi);
+            const f32x4 a4 = *reinterpret_cast<const f32x4*>(ar + 4 * vi);
+            f32x4 y;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) y[j] = (v[i][j] - mean) * rstd * (m4[j] + add_one) + a4[j];
+            if (out_kind == 1) {
+                *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(out) + t * ldo + 4 * vi) = y;
+            } else {
+                unsigned short* ob = reinterpret_cast<unsigned short*>(out) + t * ldo;
+                u32x2 hi;
+                hi[0] = pack_bf16x2(y[0], y[1]);
+                hi[1] = pack_bf16x2(y[2], y[3]);
+                *reinterpret_cast<u32x2*>(ob + 4 * vi) = hi;
+                if (out_kind == 2) {
+                    // [hi | hi | lo]: lo = bf16(y - float(hi)); A'=[hi,hi,lo] x W'=[Whi,Wlo,Whi] ~ fp32 product
+                    *reinterpret_cast<u32x2*>(ob + C + 4 * vi) = hi;
+                    float r[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) r[j] = y[j] - bf16_to_f32(f32_to_bf16(y[j]));
+                    u32x2 lo;
+                    lo[0] = pack_bf16x2(r[0], r[1]);
+                    lo[1] = pack_bf16x2(r[2], r[3]);
+                    *reinterpret_cast<u32x2*>(ob + 2 * C + 4 * vi) = lo;
+                }
+            }
+        }
+    }
+}
+
+// RMSNorm(+RoPE) in place. Each thread owns NV 16-byte vectors (8 bf16) of the row:
+// vector index vi = tid + i*NT, i < NV; part(vi) = vi / (C/8) is wave-uniform since (C/8)%64==0.
+template <int NV>
+__global__ __launch_bounds__(NT) void rmsnorm_rope_kernel(unsigned short* __restrict__ buf, int64_t ld, int C,
+                                                          int nparts, const float* __restrict__ w, float eps,
+                                                          const float* __restrict__ rope /*[T,64,2] or null*/) {
+    __shared__ float red[8];
+    const int64_t t = blockIdx.x;
+    unsigned short* row = buf + t * ld;
+    const int vpp = C >> 3;  // vectors per part
+    const int nvec = vpp * nparts;
+    u16x8 v[NV];
+    float ss[2] = {0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int vi = threadIdx.x + i * NT;
+        if (vi < nvec) {
+            v[i] = *reinterpret_cast<const u16x8*>(row + 8 * vi);
+            float a = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float f = bf16_to_f32(v[i][j]);
+                a += f * f;
+            }
+            if (vi < vpp) ss[0] += a; else ss[1] += a;
+        }
+    }
+    const float s0 = block_sum(ss[0], red);
+    float s1 = 0.f;
+    if (nparts > 1) s1 = block_sum(ss[1], red);
+    const float r0 = rsqrtf(s0 / (float)C + eps);
+    const float r1 = rsqrtf(s1 / (float)C + eps);
+    const float* rp = rope ? rope + t * 128 : nullptr;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int vi = threadIdx.x + i * NT;
+        if (vi < nvec) {
+            const bool p1 = vi >= vpp;
+            const float r = p1 ? r1 : r0;
+            const int c0 = 8 * vi;  // column in [0, nparts*C) ; weight index identical
+            const f32x4 w0 = *reinterpret_cast<const f32x4*>(w + c0);
+            const f32x4 w1 = *reinterpret_cast<const f32x4*>(w + c0 + 4);
+            float y[8];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                y[j] = bf16_to_f32(v[i][j]) * r * w0[j];
+                y[4 + j] = bf16_to_f32(v[i][4 + j]) * r * w1[j];
+            }
+            if (rp) {
+                // element e within the head: (c0 % 128) .. +7  -> complex pairs (c0%128)/2 .. +3
+                const int pr = (c0 & 127) >> 1;
+                const f32x4 cs0 = *reinterpret_cast<const f32x4*>(rp + 2 * pr);      // cos0 sin0 cos1 sin1
+                const f32x4 cs1 = *reinterpret_cast<const f32x4*>(rp + 2 * pr + 4);  // cos2 sin2 cos3 sin3
+                const float cs[8] = {cs0[0], cs0[1], cs0[2], cs0[3], cs1[0], cs1[1], cs1[2], cs1[3]};
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    const float a = y[2 * p], b = y[2 * p + 1];
+                    const float c = cs[2 * p], s = cs[2 * p + 1];
+                    y[2 * p] = a * c - b * s;
+                    y[2 * p + 1] = a * s + b * c;
+                }
+            }
+            u32x4 o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = pack_bf16x2(y[2 * j], y[2 * j + 1]);
+            *reinterpret_cast<u32x4*>(row + 8 * vi) = o;
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int yume_adaln_modulate(const float* x, int64_t ldx, int64_t T, int64_t C, float eps, const float* mul,
+                                   const float* add, int64_t tab_stride, const int32_t* row_idx, int add_one,
+                                   void* out, int64_t ldo, int out_kind, void* stream) {
+    YUME_REQUIRE(x && mul && add && out, "adaln_modulate: NULL pointer");
+    YUME_REQUIRE(T >= 0 && C > 0 && (C % 8) == 0 && C <= 8192, "adaln_modulate: C=%lld must be a multiple of 8 and <= 8192", (long long)C);
+    YUME_REQUIRE(out_kind >= 0 && out_kind <= 2, "adaln_modulate: out_kind %d", out_kind);
+    YUME_REQUIRE((ldx % 4) == 0 && (ldo % 4) == 0 && (tab_stride % 4) == 0, "adaln_modulate: strides must be multiples of 4");
+    if (T == 0) return YUME_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const float one = add_one ? 1.f : 0.f;
+    dim3 grid((unsigned)T), block(NT);
+    if (C <= NT * 4 * 3)
+        hipLaunchKernelGGL(adaln_kernel<3>, grid, block, 0, st, x, ldx, (int)C, eps, mul, add, tab_stride, row_idx, one, out, ldo, out_kind);
+    else if (C <= NT * 4 * 5)
+        hipLaunchKernelGGL(adaln_kernel<5>, grid, block, 0, st, x, ldx, (int)C, eps, mul, add, tab_stride, row_idx, one, out, ldo, out_kind);
+    else
+        hipLaunchKernelGGL(adaln_kernel<8>, grid, block, 0, st, x, ldx, (int)C, eps, mul, add, tab_stride, row_idx, one, out, ldo, out_kind);
+    YUME_CHECK_LAUNCH("adaln_modulate");
+    return YUME_OK;
+}
+
+extern "C" int yume_rmsnorm_rope(void* buf, int64_t ld, int64_t T, int64_t C, int nparts, const float* w, float eps,
+                                 const float* rope, int64_t D, void* stream) {
+    YUME_REQUIRE(buf && w, "rmsnorm_rope: NULL pointer");
+    YUME_REQUIRE(nparts == 1 || nparts == 2, "rmsnorm_rope: nparts must be 1 or 2");
+    YUME_REQUIRE(C > 0 && (C % 512) == 0 && C <= 8192, "rmsnorm_rope: C=%lld must be a multiple of 512 and <= 8192", (long long)C);
+    YUME_REQUIRE(rope == nullptr || D == 128, "rmsnorm_rope: RoPE needs head_dim 128");
+    YUME_REQUIRE((ld % 8) == 0, "rmsnorm_rope: ld must be a multiple of 8");
+    if (T == 0) return YUME_OK;
+    hipStream_t st = (hipStream_t)stream;
+    unsigned short* b = reinterpret_cast<unsigned short*>(buf);
+    const int64_t nvec = (C / 8) * nparts;
+    dim3 grid((unsigned)T), block(NT);
+    if (nvec <= NT * 2)
+        hipLaunchKernelGGL(rmsnorm_rope_kernel<2>, grid, block, 0, st, b, ld, (int)C, nparts, w, eps, rope);
+    else if (nvec <= NT * 3)
+        hipLaunchKernelGGL(rmsnorm_rope_kernel<3>, grid, block, 0, st, b, ld, (int)C, nparts, w, eps, rope);
+    else if (nvec <= NT * 5)
+        hipLaunchKernelGGL(rmsnorm_rope_kernel<5>, grid, block, 0, st, b, ld, (int)C, nparts, w, eps, rope);
+    else
+        hipLaunchKernelGGL(rmsnorm_rope_kernel<8>, grid, block, 0, st, b, ld, (int)C, nparts, w, eps, rope);
+    YUME_CHECK_LAUNCH("rmsnorm_rope");
+    return YUME_OK;
+}

@@ -1,0 +1,362 @@
+"""DiT denoise engine: drives the HIP kernels (yume_amd.ops) for one WanModel forward.
+
+The nn.Module classes in yume_amd/wan23/modules/model.py and yume_amd/wan/modules/model.py only hold the
+parameters under the reference's state_dict key names and keep the reference call signatures; all compute
+goes through this engine:
+
+    pack (once)   q|k|v weights concatenated to one [3C, C] bf16 matrix, cross k|v to [2C, C], patch-embed
+                  kernels flattened to GEMM operands, head weight split hi/lo for the fp32-accurate head GEMM,
+                  block modulations stacked.
+    per clip      FramePack plan, per-token RoPE (cos, sin) table and timestep-row selector, cached on device.
+    per step      patch gather+GEMM -> fp32 residual stream; time MLP on the R distinct timesteps only
+                  (R = 2 on the FramePack path: clean history and the current sigma) instead of all L tokens;
+                  text MLP; per block: adaLN -> fused QKV GEMM (V written K-major) -> RMSNorm+RoPE ->
+                  attention -> o-proj GEMM with gate*y+residual epilogue -> norm3 -> cross-attention ->
+                  adaLN -> FFN (GELU fused) -> gate/residual epilogue; head; unpatchify.
+
+HBM layout (L tokens, C hidden): residual stream x fp32 [L, C]; GEMM operands bf16 row-major [L, K];
+q|k bf16 [L, 2C]; V^T bf16 [C, Lpad] (K-major, per head 128 rows); modulation tables fp32 [blocks, R, 6, C].
+"""
+import math
+
+import torch
+
+from . import framepack, ops
+from .ops import EPI_BF16, EPI_BF16_GELU, EPI_BF16_GELU_ERF, EPI_BF16_SPLITT, EPI_F32, EPI_RESID
+
+
+def _round_up(a, b):
+    return (a + b - 1) // b * b
+
+
+class DiTEngine:
+    def __init__(self, model, family):
+        assert family in ("wan23", "wan")
+        self.model = model
+        self.family = family
+        self._packed_key = None
+        self._ws = {}
+        self._plan_cache = {}
+
+    # ------------------------------------------------------------------ weights
+    def _param_key(self):
+        return tuple((p.data_ptr(), p._version, p.dtype) for p in self.model.parameters())
+
+    def _pack(self):
+        m = self.model
+        dev = m.patch_embedding.weight.device
+        if dev.type != "cuda":
+            raise RuntimeError("yume_amd WanModel must live on the GPU ('cuda') — there is no CPU path")
+        C = m.dim
+
+        def bf(w):
+            return w.detach().to(torch.bfloat16).contiguous()
+
+        def f32(w):
+            return w.detach().to(torch.float32).contiguous()
+
+        def padk(w2d):
+            K = w2d.shape[1]
+            Kp = _round_up(K, 64)
+            if Kp != K:
+                w2d = torch.cat([w2d, w2d.new_zeros(w2d.shape[0], Kp - K)], dim=1)
+            return w2d.contiguous()
+
+        P = {}
+        # patch embeddings (levels 0..4 + the 2x_f pre-conv); only those attached to the module are packed
+        P["pe"] = {}
+        for lvl, suf in enumerate(framepack.LEVEL_SUFFIX):
+            conv = getattr(m, "patch_embedding" + suf, None)
+            if conv is not None:
+                P["pe"][lvl] = (padk(bf(conv.weight.flatten(1))), f32(conv.bias))
+        conv = getattr(m, "patch_embedding_2x_f", None)
+        if conv is not None:
+            P["pe"]["2x_f"] = (padk(bf(conv.weight.flatten(1))), f32(conv.bias))
+        te, tm, tp = m.text_embedding, m.time_embedding, m.time_projection
+        P["text"] = (bf(te[0].weight), f32(te[0].bias), bf(te[2].weight), f32(te[2].bias))
+        # fp32 islands keep the parameter's own precision (bf16 if the model was cast, else fp32)
+        keep = lambda w: w.detach().contiguous() if w.dtype in (torch.float32, torch.bfloat16) else f32(w)
+        P["time"] = (keep(tm[0].weight), f32(tm[0].bias), keep(tm[2].weight), f32(tm[2].bias),
+                     keep(tp[1].weight), f32(tp[1].bias))
+        if self.family == "wan":
+            pr = m.img_emb.proj
+            P["img"] = (f32(pr[0].weight), f32(pr[0].bias), bf(pr[1].weight), f32(pr[1].bias), bf(pr[3].weight),
+                        f32(pr[3].bias), f32(pr[4].weight), f32(pr[4].bias))
+        blocks = []
+        for b in m.blocks:
+            sa, ca = b.self_attn, b.cross_attn
+            d = {
+                "wqkv": bf(torch.cat([sa.q.weight, sa.k.weight, sa.v.weight], dim=0)),
+                "bqkv": f32(torch.cat([sa.q.bias, sa.k.bias, sa.v.bias])),
+                "nqk": f32(torch.cat([sa.norm_q.weight, sa.norm_k.weight])),
+                "wo": bf(sa.o.weight), "bo": f32(sa.o.bias),
+                "wq_c": bf(ca.q.weight), "bq_c": f32(ca.q.bias), "nq_c": f32(ca.norm_q.weight),
+                "wkv_c": bf(torch.cat([ca.k.weight, ca.v.weight], dim=0)),
+                "bkv_c": f32(torch.cat([ca.k.bias, ca.v.bias])), "nk_c": f32(ca.norm_k.weight),
+                "wo_c": bf(ca.o.weight), "bo_c": f32(ca.o.bias),
+                "w1": bf(b.ffn[0].weight), "b1": f32(b.ffn[0].bias),
+                "w2": bf(b.ffn[2].weight), "b2": f32(b.ffn[2].bias),
+            }
+            if getattr(b.norm3, "weight", None) is not None:
+                d["n3w"], d["n3b"] = f32(b.norm3.weight), f32(b.norm3.bias)
+            if self.family == "wan":
+                d["wkv_i"] = bf(torch.cat([ca.k_img.weight, ca.v_img.weight], dim=0))
+                d["bkv_i"] = f32(torch.cat([ca.k_img.bias, ca.v_img.bias]))
+                d["nk_i"] = f32(ca.norm_k_img.weight)
+            blocks.append(d)
+        P["blocks"] = blocks
+        P["mod_all"] = f32(torch.cat([b.modulation.reshape(1, 6 * C) for b in m.blocks], dim=0))
+        P["mod_head"] = f32(m.head.modulation.reshape(2, C))
+        wh = m.head.head.weight.detach().float()
+        hi = wh.to(torch.bfloat16)
+        lo = (wh - hi.float()).to(torch.bfloat16)
+        P["whead"] = torch.cat([hi, lo, hi], dim=1).contiguous()   # pairs with A' = [hi | hi | lo]
+        P["bhead"] = f32(m.head.head.bias)
+        self.P = P
+        self.dev = dev
+
+    def ensure_packed(self):
+        key = self._param_key()
+        if key != self._packed_key:
+            self._pack()
+            self._packed_key = key
+
+    # ------------------------------------------------------------------ workspaces / per-clip tables
+    def _buf(self, name, shape, dtype):
+        t = self._ws.get(name)
+        if t is None or tuple(t.shape) != tuple(shape) or t.dtype != dtype or t.device != self.dev:
+            t = torch.empty(shape, dtype=dtype, device=self.dev)
+            self._ws[name] = t
+        return t
+
+    def _clip_tables(self, key, build):
+        v = self._plan_cache.get(key)
+        if v is None:
+            if len(self._plan_cache) > 64:
+                self._plan_cache.clear()
+            v = build()
+            self._plan_cache[key] = v
+        return v
+
+    # ------------------------------------------------------------------ pieces
+    def _embed_group(self, u, g, xs_rows):
+        """patch-embed frames [g.f0, g.f0+g.nf) of u [Cin,F,H,W] at level g.level into xs_rows (fp32 [ntok, C])."""
+        P = self.P["pe"]
+        if g.level == 5:
+            w, b = P["2x_f"]
+            Cin = u.shape[0]
+            h4, w4 = -(-u.shape[2] // 4), -(-u.shape[3] // 4)
+            a = self._buf("pe_a5", (g.nf * h4 * w4, w.shape[1]), torch.bfloat16)
+            ops.patch_gather(u, g.f0, g.nf, 4, 4, a)
+            mid = self._buf("pe_mid", (g.nf * h4 * w4, Cin), torch.float32)
+            ops.gemm_bf16(a, w, b, mid, EPI_F32)
+            # layout change only: token-major [f,h,w,c] -> [c,f,h,w] for the second gather
+            u = mid.view(g.nf, h4, w4, Cin).permute(3, 0, 1, 2).contiguous()
+            f0, lvl = 0, 4
+        else:
+            f0, lvl = g.f0, g.level
+        if lvl not in P:
+            raise RuntimeError(f"patch_embedding{framepack.LEVEL_SUFFIX[lvl]} is needed for this history length "
+                               "but is not attached to the model")
+        w, b = P[lvl]
+        k = 2 << lvl
+        a = self._buf(f"pe_a{lvl}_{g.ntok}", (g.ntok, w.shape[1]), torch.bfloat16)
+        ops.patch_gather(u, f0, g.nf, k, k, a)
+        ops.gemm_bf16(a, w, b, xs_rows, EPI_F32)
+
+    def _time_rows(self, t64, t_index, R):
+        """e [R, C], e0 [R, 6C] for the R distinct timesteps (fp32 islands of the reference)."""
+        C = self.model.dim
+        w0, b0, w2, b2, wp, bp = self.P["time"]
+        e = self._buf("t_e", (R, C), torch.float32)
+        e0 = self._buf("t_e0", (R, 6 * C), torch.float32)
+        for r0 in range(0, R, 8):
+            r1 = min(R, r0 + 8)
+            n = r1 - r0
+            s = self._buf("t_sin", (8, self.model.freq_dim), torch.float32)[:n]
+            h = self._buf("t_h", (8, C), torch.float32)[:n]
+            idx = t_index[r0:r1] if t_index is not None else None
+            tt = t64 if t_index is not None else t64[r0:r1]
+            ops.sinusoidal_embed(tt, idx, n, self.model.freq_dim, s)
+            ops.linear_smallm_f32(s, w0, b0, h, in_act=0, out_act=1)          # Linear -> SiLU
+            ops.linear_smallm_f32(h, w2, b2, e[r0:r1])                        # Linear
+            ops.linear_smallm_f32(e[r0:r1], wp, bp, e0[r0:r1], in_act=1)      # SiLU -> Linear
+        return e, e0
+
+    def _text_ctx(self, context, out_rows):
+        m = self.model
+        w0, b0, w2, b2 = self.P["text"]
+        n = context.shape[0]
+        if n > m.text_len:
+            raise RuntimeError(f"context has {n} tokens > text_len {m.text_len}")
+        cpad = self._buf("ctx_in", (m.text_len, m.text_dim), torch.bfloat16)
+        ops.cast_bf16(context.to(device=self.dev, dtype=torch.float32).contiguous(), n, cpad)
+        hid = self._buf("ctx_hid", (m.text_len, m.dim), torch.bfloat16)
+        ops.gemm_bf16(cpad, w0, b0, hid, EPI_BF16_GELU)
+        ops.gemm_bf16(hid, w2, b2, out_rows, EPI_BF16)
+
+    def _img_ctx(self, clip_fea, out_rows):
+        C = self.model.dim
+        lw, lb, w1, b1, w3, b3, l4w, l4b = self.P["img"]
+        x = clip_fea.to(device=self.dev, dtype=torch.float32).reshape(-1, clip_fea.shape[-1]).contiguous()
+        n, d = x.shape
+        a = self._buf("img_a", (n, d), torch.bfloat16)
+        ops.adaln_modulate(x, lw, lb, 0, None, False, a, 0, eps=1e-5)         # nn.LayerNorm default eps
+        h = self._buf("img_h", (n, d), torch.bfloat16)
+        ops.gemm_bf16(a, w1, b1, h, EPI_BF16_GELU_ERF)
+        y = self._buf("img_y", (n, C), torch.float32)
+        ops.gemm_bf16(h, w3, b3, y, EPI_F32)
+        ops.adaln_modulate(y, l4w, l4b, 0, None, False, out_rows, 0, eps=1e-5)
+
+    def _cross(self, hc, ctx_rows, nk, wkv, bkv, nk_w, ac, L, accumulate):
+        """one cross-attention over ctx_rows (bf16 [nk, C]); result into ac (bf16 [L, C])."""
+        C, H = self.model.dim, self.model.num_heads
+        eps = self.model.eps
+        kc = self._buf(f"kc_{nk}", (nk, C), torch.bfloat16)
+        vct = self._buf(f"vct_{nk}", (C, _round_up(nk, 8)), torch.bfloat16)
+        ops.gemm_bf16(ctx_rows, wkv, bkv, kc, EPI_BF16_SPLITT, out_t=vct, n_split=C)
+        ops.rmsnorm_rope(kc, C, 1, nk_w, eps)
+        ops.attn_fwd(hc, kc, vct, ac, L, nk, H, accumulate=accumulate)
+
+    def _blocks(self, xs, L, tab, row_idx, R, rope, n_rope, ctx, n_img):
+        """xs fp32 [L, C] in/out. tab fp32 [nb, R, 6, C]; rope fp32 [n_rope, 64, 2] (n_rope == L here)."""
+        m = self.model
+        C, H, Fd, eps = m.dim, m.num_heads, m.ffn_dim, m.eps
+        Lp = _round_up(L, 8)
+        h = self._buf("h", (L, C), torch.bfloat16)
+        qk = self._buf("qk", (L, 2 * C), torch.bfloat16)
+        vt = self._buf("vt", (C, Lp), torch.bfloat16)
+        att = self._buf("att", (L, C), torch.bfloat16)
+        ff = self._buf("ff", (L, Fd), torch.bfloat16)
+        ts = 6 * C  # table row stride
+        for i, d in enumerate(self.P["blocks"]):
+            tb = tab[i]                      # [R, 6, C]
+            shift_sa, scale_sa, gate_sa = tb[:, 0], tb[:, 1], tb[:, 2]
+            shift_ff, scale_ff, gate_ff = tb[:, 3], tb[:, 4], tb[:, 5]
+            # --- self attention
+            ops.adaln_modulate(xs, scale_sa, shift_sa, ts, row_idx, True, h, 0, eps)
+            ops.gemm_bf16(h, d["wqkv"], d["bqkv"], qk, EPI_BF16_SPLITT, out_t=vt, n_split=2 * C)
+            if n_rope == L:
+                ops.rmsnorm_rope(qk, C, 2, d["nqk"], eps, rope)
+            else:
+                ops.rmsnorm_rope(qk[:n_rope], C, 2, d["nqk"], eps, rope)
+                ops.rmsnorm_rope(qk[n_rope:], C, 2, d["nqk"], eps, None)
+            ops.attn_fwd(qk[:, :C], qk[:, C:], vt, att, L, L, H)
+            ops.gemm_bf16(att, d["wo"], d["bo"], xs, EPI_RESID, gate=gate_sa, gate_stride=ts, row_idx=row_idx)
+            # --- cross attention
+            if "n3w" in d:
+                ops.adaln_modulate(xs, d["n3w"], d["n3b"], 0, None, False, h, 0, eps)
+            else:
+                ops.cast_bf16(xs, L, h)
+            ops.gemm_bf16(h, d["wq_c"], d["bq_c"], qk[:, :C], EPI_BF16)
+            ops.rmsnorm_rope(qk[:, :C], C, 1, d["nq_c"], eps)
+            ntxt = ctx.shape[0] - n_img
+            self._cross(qk[:, :C], ctx[n_img:], ntxt, d["wkv_c"], d["bkv_c"], d["nk_c"], att, L, False)
+            if n_img:
+                self._cross(qk[:, :C], ctx[:n_img], n_img, d["wkv_i"], d["bkv_i"], d["nk_i"], att, L, True)
+            ops.gemm_bf16(att, d["wo_c"], d["bo_c"], xs, EPI_RESID)
+            # --- FFN
+            ops.adaln_modulate(xs, scale_ff, shift_ff, ts, row_idx, True, h, 0, eps)
+            ops.gemm_bf16(h, d["w1"], d["b1"], ff, EPI_BF16_GELU)
+            ops.gemm_bf16(ff, d["w2"], d["b2"], xs, EPI_RESID, gate=gate_ff, gate_stride=ts, row_idx=row_idx)
+
+    def _head(self, xs_new, row_idx_new, e, R, grid):
+        """xs_new fp32 [Ln, C] -> fp32 [Cout, F, 2*Hp, 2*Wp]."""
+        m = self.model
+        C, Co = m.dim, m.out_dim
+        Ln = xs_new.shape[0]
+        # (head.modulation [2, C] + e [R, C]) -> th[j, r, :]: j = 0 shift, 1 scale   (model.py:344)
+        th = self._buf("tab_head", (2, R, C), torch.float32)
+        ops.modulation_table(self.P["mod_head"], e, th)
+        a3 = self._buf("head_a", (Ln, 3 * C), torch.bfloat16)
+        ops.adaln_modulate(xs_new, th[1], th[0], C, row_idx_new, True, a3, 2, m.eps)
+        y = self._buf("head_y", (Ln, 4 * Co), torch.float32)
+        ops.gemm_bf16(a3, self.P["whead"], self.P["bhead"], y, EPI_F32)
+        Fr, Hp, Wp = grid
+        out = torch.empty((Co, Fr, 2 * Hp, 2 * Wp), dtype=torch.float32, device=self.dev)
+        ops.unpatchify(y, Fr, Hp, Wp, 2, 2, Co, out)
+        return out
+
+    # ------------------------------------------------------------------ one sample forward
+    @torch.no_grad()
+    def forward_one(self, u, t, context, clip_fea=None, packed=True, lfz=8, n_sel=None):
+        """u [Cin, F, H, W] (fp32|bf16, x and y already concatenated); t tensor; context [Ltxt, text_dim].
+        Returns fp32 [Cout, F', H, W]."""
+        self.ensure_packed()
+        m = self.model
+        C, D = m.dim, m.dim // m.num_heads
+        if D != 128:
+            raise RuntimeError("yume_amd attention kernels are built for head_dim 128")
+        u = u.to(self.dev)
+        if u.dtype not in (torch.float32, torch.bfloat16):
+            u = u.float()
+        u = u.contiguous()
+        Cin, F, H, W = u.shape
+        if Cin != m.in_dim:
+            raise RuntimeError(f"input has {Cin} channels, model in_dim is {m.in_dim}")
+        t64 = t.to(device=self.dev, dtype=torch.float64).reshape(-1).contiguous()
+
+        if packed:
+            def build():
+                plan = framepack.pack_plan(F, H, W, lfz, n_sel)
+                rope = framepack.plan_rope(plan, D).to(self.dev)
+                ridx = torch.cat([torch.zeros(plan.n_hist_tok, dtype=torch.int32),
+                                  torch.ones(plan.n_new_tok, dtype=torch.int32)]).to(self.dev)
+                return plan, rope, ridx
+            plan, rope, ridx = self._clip_tables(("p", F, H, W, lfz, n_sel), build)
+            L, n_hist = plan.seq_len, plan.n_hist_tok
+            groups, grid = plan.groups, plan.new_grid
+        else:
+            def build():
+                hp, wp = -(-H // 2), -(-W // 2)
+                rope = framepack.rope_cos_sin([(0, F, hp, wp)], D).to(self.dev)
+                return framepack.Group(0, F, 0, hp, wp), rope
+            g0, rope = self._clip_tables(("u", F, H, W), build)
+            L, n_hist = g0.ntok, 0
+            groups, grid = [g0], (F, g0.hp, g0.wp)
+            ridx = None
+
+        # --- timestep rows
+        if self.family == "wan":
+            if t64.numel() != 1:
+                raise RuntimeError("the 14B-arch model takes one scalar timestep per sample")
+            R, t_index, row_idx = 1, None, None
+        elif packed:
+            if t64.numel() < 2:
+                raise RuntimeError("FramePack path expects a per-token timestep vector (t[0] history, t[-1] new)")
+            t_index = self._clip_tables(("ti", t64.numel()), lambda: torch.tensor(
+                [0, t64.numel() - 1], dtype=torch.int32, device=self.dev))
+            R, row_idx = 2, ridx
+        elif t64.numel() == 1:
+            R, t_index, row_idx = 1, None, None
+        else:
+            # arbitrary per-token timesteps (plain path): evaluate the distinct values only
+            if t64.numel() < L:
+                raise RuntimeError(f"per-token t has {t64.numel()} entries for {L} tokens")
+            uniq, inv = torch.unique(t64[:L], return_inverse=True)
+            t64, t_index, R = uniq.contiguous(), None, int(uniq.numel())
+            row_idx = inv.to(torch.int32).contiguous()
+
+        # --- embeddings
+        xs = self._buf("xs", (L, C), torch.float32)
+        off = 0
+        for g in groups:
+            self._embed_group(u, g, xs[off:off + g.ntok])
+            off += g.ntok
+        e, e0 = self._time_rows(t64, t_index, R)
+        nb = len(self.P["blocks"])
+        tab = self._buf("tab", (nb, R, 6 * C), torch.float32)
+        ops.modulation_table(self.P["mod_all"], e0, tab)
+        n_img = 0
+        if self.family == "wan":
+            if clip_fea is None:
+                raise RuntimeError("clip_fea is required by the i2v model")
+            n_img = clip_fea.reshape(-1, clip_fea.shape[-1]).shape[0]
+        ctx = self._buf("ctx", (n_img + m.text_len, C), torch.bfloat16)
+        if n_img:
+            self._img_ctx(clip_fea, ctx[:n_img])
+        self._text_ctx(context, ctx[n_img:])
+
+        self._blocks(xs, L, tab.view(nb, R, 6, C), row_idx, R, rope, L, ctx, n_img)
+        ridx_new = row_idx[n_hist:] if row_idx is not None else None
+        return self._head(xs[n_hist:], ridx_new, e, R, grid)

@@ -1,0 +1,185 @@
+"""Tensor-level wrappers over the C-ABI (include/yume_hip.h).
+
+torch is used for device memory and the current HIP stream only: every function here validates
+its tensors, passes raw device pointers + sizes to libyume_hip.so and raises RuntimeError on failure.
+"""
+import math
+
+import torch
+
+from . import _lib
+
+EPI_BF16, EPI_BF16_GELU, EPI_F32, EPI_RESID, EPI_BF16_SPLITT, EPI_BF16_GELU_ERF = 0, 1, 2, 3, 4, 5
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _dev(t, name, dtype=None):
+    if not isinstance(t, torch.Tensor) or t.device.type != "cuda":
+        raise RuntimeError(f"yume_amd: {name} must be a device ('cuda') tensor — this path has no CPU fallback")
+    if dtype is not None and t.dtype != dtype:
+        raise RuntimeError(f"yume_amd: {name} must be {dtype}, got {t.dtype}")
+    return t
+
+
+def _rows(t, name):
+    """2-D view parameters (ptr, ld) of a tensor whose last dim is contiguous."""
+    if t.dim() != 2 or t.stride(1) != 1:
+        raise RuntimeError(f"yume_amd: {name} must be 2-D with a contiguous last dim, got shape {tuple(t.shape)} stride {t.stride()}")
+    return t.data_ptr(), t.stride(0)
+
+
+def _ptr(t):
+    return t.data_ptr() if t is not None else None
+
+
+def adaln_modulate(x, mul, add, tab_stride, row_idx, add_one, out, out_kind=0, eps=1e-6):
+    """out = LN(x) * (mul[row] + add_one) + add[row]; x fp32 [T,C]; mul/add fp32 table views (first row)."""
+    lib = _lib.load()
+    _dev(x, "x", torch.float32)
+    xp, ldx = _rows(x, "x")
+    T, C = x.shape
+    op, ldo = _rows(out, "out")
+    rc = lib.yume_adaln_modulate(xp, ldx, T, C, eps, mul.data_ptr(), add.data_ptr(), tab_stride, _ptr(row_idx),
+                                 1 if add_one else 0, op, ldo, out_kind, _stream())
+    _lib.check(rc, "yume_adaln_modulate")
+    return out
+
+
+def gemm_bf16(a, w, bias, out, epi=EPI_BF16, gate=None, gate_stride=0, row_idx=None, out_t=None, n_split=0,
+              variant=0):
+    """acc = a @ w.T (a bf16 [M,K], w bf16 [N,K]); epilogue selected by `epi` (see yume_hip.h)."""
+    lib = _lib.load()
+    _dev(a, "a", torch.bfloat16)
+    _dev(w, "w", torch.bfloat16)
+    ap, lda = _rows(a, "a")
+    wp, ldw = _rows(w, "w")
+    M, K = a.shape
+    N, K2 = w.shape
+    if K != K2:
+        raise RuntimeError(f"yume_amd.gemm_bf16: K mismatch {K} vs {K2}")
+    op, ldo = _rows(out, "out")
+    tp, ldt = (None, 0)
+    if out_t is not None:
+        tp, ldt = _rows(out_t, "out_t")
+    rc = lib.yume_gemm_bf16(ap, lda, wp, ldw, _ptr(bias), M, N, K, epi, op, ldo, _ptr(gate), gate_stride,
+                            _ptr(row_idx), tp, ldt, n_split, variant, _stream())
+    _lib.check(rc, "yume_gemm_bf16")
+    return out
+
+
+def rmsnorm_rope(buf, C, nparts, w, eps=1e-6, rope=None, head_dim=128):
+    """in-place RMSNorm over C (+RoPE) on the first nparts*C columns of bf16 `buf` [T, >=nparts*C]."""
+    lib = _lib.load()
+    _dev(buf, "buf", torch.bfloat16)
+    bp, ld = _rows(buf, "buf")
+    T = buf.shape[0]
+    rc = lib.yume_rmsnorm_rope(bp, ld, T, C, nparts, w.data_ptr(), eps, _ptr(rope), head_dim, _stream())
+    _lib.check(rc, "yume_rmsnorm_rope")
+    return buf
+
+
+def attn_fwd(q, k, vt, out, Lq, Lk, H, scale=None, accumulate=False, variant=0):
+    """out[Lq, H*128] = softmax(q k^T * scale) v ; q,k token-major bf16 2-D views, vt K-major [H*128, >=Lk]."""
+    lib = _lib.load()
+    _dev(q, "q", torch.bfloat16)
+    _dev(k, "k", torch.bfloat16)
+    _dev(vt, "vt", torch.bfloat16)
+    _dev(out, "out", torch.bfloat16)
+    qp, ldq = _rows(q, "q")
+    kp, ldk = _rows(k, "k")
+    vp, ldv = _rows(vt, "vt")
+    op, ldo = _rows(out, "out")
+    if scale is None:
+        scale = 1.0 / math.sqrt(128.0)
+    rc = lib.yume_attn_fwd(qp, ldq, kp, ldk, vp, ldv, op, ldo, Lq, Lk, H, scale, 1 if accumulate else 0, variant,
+                           _stream())
+    _lib.check(rc, "yume_attn_fwd")
+    return out
+
+
+def linear_smallm_f32(x, w, bias, out, in_act=0, out_act=0, add_table=None):
+    lib = _lib.load()
+    _dev(x, "x", torch.float32)
+    R, K = x.shape
+    N = w.shape[0]
+    if not (x.is_contiguous() and w.is_contiguous() and out.is_contiguous()):
+        raise RuntimeError("yume_amd.linear_smallm_f32: tensors must be contiguous")
+    if w.dtype not in (torch.float32, torch.bfloat16) or w.shape[1] != K:
+        raise RuntimeError("yume_amd.linear_smallm_f32: bad weight")
+    rc = lib.yume_linear_smallm_f32(x.data_ptr(), R, K, w.data_ptr(), 1 if w.dtype == torch.bfloat16 else 0,
+                                    _ptr(bias), N, in_act, out_act, _ptr(add_table), out.data_ptr(), _stream())
+    _lib.check(rc, "yume_linear_smallm_f32")
+    return out
+
+
+def modulation_table(tab, e0, out):
+    """out[b, r, :] = tab[b, :] + e0[r, :]  (fp32, contiguous)."""
+    lib = _lib.load()
+    _dev(tab, "tab", torch.float32)
+    _dev(e0, "e0", torch.float32)
+    B, W = tab.shape
+    R = e0.shape[0]
+    if not (tab.is_contiguous() and e0.is_contiguous() and out.is_contiguous()) or e0.shape[1] != W:
+        raise RuntimeError("yume_amd.modulation_table: bad layout")
+    rc = lib.yume_modulation_table(tab.data_ptr(), e0.data_ptr(), B, R, W, out.data_ptr(), _stream())
+    _lib.check(rc, "yume_modulation_table")
+    return out
+
+
+def sinusoidal_embed(t, t_index, R, dim, out):
+    lib = _lib.load()
+    _dev(t, "t", torch.float64)
+    rc = lib.yume_sinusoidal_embed(t.data_ptr(), _ptr(t_index), R, dim, out.data_ptr(), _stream())
+    _lib.check(rc, "yume_sinusoidal_embed")
+    return out
+
+
+def patch_gather(x, f0, nf, kh, kw, out):
+    """x [Cin,F,H,W] fp32|bf16 contiguous -> out bf16 [nf*ceil(H/kh)*ceil(W/kw), Kp]."""
+    lib = _lib.load()
+    _dev(x, "x")
+    if not x.is_contiguous() or x.dim() != 4:
+        raise RuntimeError("yume_amd.patch_gather: x must be contiguous [Cin,F,H,W]")
+    if x.dtype not in (torch.float32, torch.bfloat16):
+        raise RuntimeError("yume_amd.patch_gather: x must be fp32 or bf16")
+    Cin, F, H, W = x.shape
+    op, Kp = _rows(out, "out")
+    rc = lib.yume_patch_gather(x.data_ptr(), 1 if x.dtype == torch.bfloat16 else 0, Cin, F, H, W, f0, nf, kh, kw, op,
+                               Kp, _stream())
+    _lib.check(rc, "yume_patch_gather")
+    return out
+
+
+def unpatchify(x, Fr, Hp, Wp, ph, pw, Cout, out):
+    lib = _lib.load()
+    _dev(x, "x", torch.float32)
+    xp, ldi = _rows(x, "x")
+    rc = lib.yume_unpatchify(xp, ldi, Fr, Hp, Wp, ph, pw, Cout, out.data_ptr(), _stream())
+    _lib.check(rc, "yume_unpatchify")
+    return out
+
+
+def cast_bf16(x, rows_valid, out):
+    lib = _lib.load()
+    _dev(x, "x", torch.float32)
+    xp, ldi = _rows(x, "x")
+    op, ldo = _rows(out, "out")
+    rows, cols = out.shape
+    rc = lib.yume_cast_bf16(xp, ldi, rows_valid, rows, cols, op, ldo, _stream())
+    _lib.check(rc, "yume_cast_bf16")
+    return out
+
+
+def transpose_bf16(x, out):
+    """x [rows, cols] fp32|bf16 -> out bf16 [cols, >=rows]."""
+    lib = _lib.load()
+    _dev(x, "x")
+    xp, ldi = _rows(x, "x")
+    op, ldo = _rows(out, "out")
+    rows, cols = x.shape
+    rc = lib.yume_transpose_bf16(xp, 1 if x.dtype == torch.bfloat16 else 0, ldi, rows, cols, op, ldo, _stream())
+    _lib.check(rc, "yume_transpose_bf16")
+    return out

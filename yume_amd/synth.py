@@ -1,0 +1,143 @@
+"""Deterministic synthetic weights and inputs for tests and bench.py (there are no checkpoints offline).
+
+Every tensor is drawn from its own CPU generator seeded by (seed, crc32(key)), so the same values are
+produced regardless of module construction order, on the build container and on the GPU box alike, and
+can be loaded into the reference model, the oracle restatement and the HIP model by key.
+Scales follow the reference's init_weights() (wan23/modules/model.py:892-914) except where that would
+make a code path vanish (zero biases, zero head weight, unit norm weights): those get small random values.
+"""
+import math
+import zlib
+
+import torch
+
+# model configs: wan23/configs/wan_ti2v_5B.py:8-36 , wan/configs/wan_i2v_14B.py:9-35
+CFG_5B = dict(model_type="ti2v", patch_size=(1, 2, 2), text_len=512, in_dim=48, dim=3072, ffn_dim=14336, freq_dim=256,
+              text_dim=4096, out_dim=48, num_heads=24, num_layers=30, window_size=(-1, -1), qk_norm=True,
+              cross_attn_norm=True, eps=1e-6)
+CFG_14B = dict(model_type="i2v", patch_size=(1, 2, 2), text_len=512, in_dim=36, dim=5120, ffn_dim=13824, freq_dim=256,
+               text_dim=4096, out_dim=16, num_heads=40, num_layers=40, window_size=(-1, -1), qk_norm=True,
+               cross_attn_norm=True, eps=1e-6)
+
+
+def tiny_cfg(family, dim=512, heads=4, ffn=1024, layers=2, text_dim=256, text_len=64):
+    """A small config with head_dim 128 (the only head_dim the reference models use)."""
+    base = dict(CFG_5B if family == "wan23" else CFG_14B)
+    base.update(dim=dim, num_heads=heads, ffn_dim=ffn, num_layers=layers, text_dim=text_dim, text_len=text_len)
+    return base
+
+
+def _gen(seed, key):
+    g = torch.Generator(device="cpu")
+    g.manual_seed((seed * 1000003 + zlib.crc32(key.encode())) & 0x7FFFFFFF)
+    return g
+
+
+def _uniform(shape, a, g):
+    return (torch.rand(shape, generator=g, dtype=torch.float32) * 2 - 1) * a
+
+
+def _normal(shape, std, g):
+    return torch.randn(shape, generator=g, dtype=torch.float32) * std
+
+
+def dit_param_shapes(cfg, family, pyramid=("_2x", "_4x", "_8x", "_16x", "_2x_f")):
+    """state_dict key -> shape for WanModel (reference key names: SURVEY Appendix C)."""
+    C, Fd, Cin, Co = cfg["dim"], cfg["ffn_dim"], cfg["in_dim"], cfg["out_dim"]
+    sh = {}
+    sh["patch_embedding.weight"] = (C, Cin, 1, 2, 2)
+    sh["patch_embedding.bias"] = (C,)
+    ks = {"_2x": 4, "_4x": 8, "_8x": 16, "_16x": 32}
+    for p in pyramid:
+        if p == "_2x_f":
+            sh["patch_embedding_2x_f.weight"] = (Cin, Cin, 1, 4, 4)
+            sh["patch_embedding_2x_f.bias"] = (Cin,)
+        else:
+            sh[f"patch_embedding{p}.weight"] = (C, Cin, 1, ks[p], ks[p])
+            sh[f"patch_embedding{p}.bias"] = (C,)
+    for i, (a, b) in {"0": (cfg["text_dim"], C), "2": (C, C)}.items():
+        sh[f"text_embedding.{i}.weight"] = (b, a)
+        sh[f"text_embedding.{i}.bias"] = (b,)
+    for i, (a, b) in {"0": (cfg["freq_dim"], C), "2": (C, C)}.items():
+        sh[f"time_embedding.{i}.weight"] = (b, a)
+        sh[f"time_embedding.{i}.bias"] = (b,)
+    sh["time_projection.1.weight"] = (6 * C, C)
+    sh["time_projection.1.bias"] = (6 * C,)
+    for l in range(cfg["num_layers"]):
+        p = f"blocks.{l}."
+        sh[p + "modulation"] = (1, 6, C)
+        for att in ("self_attn", "cross_attn"):
+            for n in ("q", "k", "v", "o"):
+                sh[p + f"{att}.{n}.weight"] = (C, C)
+                sh[p + f"{att}.{n}.bias"] = (C,)
+            sh[p + f"{att}.norm_q.weight"] = (C,)
+            sh[p + f"{att}.norm_k.weight"] = (C,)
+        if family == "wan":
+            for n in ("k_img", "v_img"):
+                sh[p + f"cross_attn.{n}.weight"] = (C, C)
+                sh[p + f"cross_attn.{n}.bias"] = (C,)
+            sh[p + "cross_attn.norm_k_img.weight"] = (C,)
+        if cfg["cross_attn_norm"]:
+            sh[p + "norm3.weight"] = (C,)
+            sh[p + "norm3.bias"] = (C,)
+        sh[p + "ffn.0.weight"] = (Fd, C)
+        sh[p + "ffn.0.bias"] = (Fd,)
+        sh[p + "ffn.2.weight"] = (C, Fd)
+        sh[p + "ffn.2.bias"] = (C,)
+    sh["head.modulation"] = (1, 2, C)
+    sh["head.head.weight"] = (4 * Co, C)
+    sh["head.head.bias"] = (4 * Co,)
+    if family == "wan":
+        sh["img_emb.proj.0.weight"] = (1280,)
+        sh["img_emb.proj.0.bias"] = (1280,)
+        sh["img_emb.proj.1.weight"] = (1280, 1280)
+        sh["img_emb.proj.1.bias"] = (1280,)
+        sh["img_emb.proj.3.weight"] = (C, 1280)
+        sh["img_emb.proj.3.bias"] = (C,)
+        sh["img_emb.proj.4.weight"] = (C,)
+        sh["img_emb.proj.4.bias"] = (C,)
+    return sh
+
+
+def make_tensor(key, shape, seed, dim):
+    g = _gen(seed, key)
+    leaf = key.split(".")[-1]
+    if leaf == "modulation":
+        return _normal(shape, 1.0 / math.sqrt(dim), g)
+    if "norm" in key or key.startswith("img_emb.proj.0") or key.startswith("img_emb.proj.4"):
+        return (1.0 + _normal(shape, 0.1, g)) if leaf == "weight" else _normal(shape, 0.05, g)
+    if leaf == "bias":
+        return _normal(shape, 0.02, g)
+    if key.startswith(("text_embedding", "time_embedding", "head.head")):
+        return _normal(shape, 0.02, g)
+    # xavier-uniform on the flattened [out, fan_in] view (Linear and the patch-embed Conv3d alike)
+    fan_out = shape[0]
+    fan_in = 1
+    for s in shape[1:]:
+        fan_in *= s
+    return _uniform(shape, math.sqrt(6.0 / (fan_in + fan_out)), g)
+
+
+def make_dit_state_dict(cfg, family, seed=0, pyramid=("_2x", "_4x", "_8x", "_16x", "_2x_f"), dtype=torch.float32,
+                        device="cpu"):
+    sd = {}
+    for k, shape in dit_param_shapes(cfg, family, pyramid).items():
+        sd[k] = make_tensor(k, shape, seed, cfg["dim"]).to(device=device, dtype=dtype)
+    return sd
+
+
+def make_dit_inputs(cfg, family, F, H, W, n_text=77, seed=0):
+    """N(0,1) latents / text / CLIP embeddings on CPU (fp32). H, W are LATENT sizes."""
+    g = _gen(seed, "inputs")
+    out = {"x": torch.randn((cfg["out_dim"] if family == "wan" else cfg["in_dim"], F, H, W), generator=g),
+           "context": torch.randn((n_text, cfg["text_dim"]), generator=g)}
+    if family == "wan":
+        out["y"] = torch.randn((cfg["in_dim"] - cfg["out_dim"], F, H, W), generator=g)
+        out["clip_fea"] = torch.randn((1, 257, 1280), generator=g)
+    return out
+
+
+def sampling_sigmas(steps, shift):
+    """fastvideo/sample/sample_5b.py:502-506 get_sampling_sigmas."""
+    s = torch.linspace(1, 0, steps + 1, dtype=torch.float64)[:steps]
+    return (shift * s / (1 + (shift - 1) * s)).tolist()

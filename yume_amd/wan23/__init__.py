@@ -1,0 +1,1 @@
+from .modules.model import WanModel  # noqa: F401

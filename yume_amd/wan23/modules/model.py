@@ -1,0 +1,186 @@
+"""Drop-in WanModel for the Yume-5B-720P (Wan2.2-TI2V-5B) architecture, MI355X-native.
+
+Keeps the reference's constructor arguments, attribute names, state_dict keys and the
+`WanModel.forward(x, t, context, seq_len, enable_mask, y, latent_frame_zero, input_ids, flag)`
+signature (reference: wan23/modules/model.py:369-495,547-865) so `fastvideo/sample/sample_5b.py`,
+`webapp_single_gpu.py` and `wan23/textimage2video.py` can instantiate it unchanged. The modules below
+only OWN parameters; the arithmetic runs in hand-written HIP kernels through yume_amd.dit.DiTEngine.
+There is no PyTorch fallback: on a machine without the built extension the forward raises.
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from ...dit import DiTEngine
+
+__all__ = ["WanModel"]
+
+
+class _ScaleOnly(nn.Module):
+    """parameter holder for WanRMSNorm (reference model.py:121-137): one `weight` of size dim."""
+
+    def __init__(self, dim, eps):
+        super().__init__()
+        self.dim, self.eps = dim, eps
+        self.weight = nn.Parameter(torch.ones(dim))
+
+
+class _Affine(nn.Module):
+    """parameter holder for the affine WanLayerNorm used as norm3 (reference model.py:140-150)."""
+
+    def __init__(self, dim, eps):
+        super().__init__()
+        self.dim, self.eps = dim, eps
+        self.weight = nn.Parameter(torch.ones(dim))
+        self.bias = nn.Parameter(torch.zeros(dim))
+
+
+class _Attention(nn.Module):
+    def __init__(self, dim, num_heads, eps, with_img=False):
+        super().__init__()
+        self.dim, self.num_heads, self.head_dim, self.eps = dim, num_heads, dim // num_heads, eps
+        for name in ("q", "k", "v", "o"):
+            setattr(self, name, nn.Linear(dim, dim))
+        self.norm_q = _ScaleOnly(dim, eps)
+        self.norm_k = _ScaleOnly(dim, eps)
+        if with_img:
+            self.k_img = nn.Linear(dim, dim)
+            self.v_img = nn.Linear(dim, dim)
+            self.norm_k_img = _ScaleOnly(dim, eps)
+
+
+class WanAttentionBlock(nn.Module):
+    """Parameter layout of one DiT block (reference model.py:235-270). Its arithmetic lives in DiTEngine._blocks."""
+
+    def __init__(self, dim, ffn_dim, num_heads, window_size=(-1, -1), qk_norm=True, cross_attn_norm=False, eps=1e-6,
+                 with_img=False):
+        super().__init__()
+        if not qk_norm:
+            raise NotImplementedError("the Yume checkpoints use qk_norm=True; the HIP path fuses it")
+        self.dim, self.ffn_dim, self.num_heads, self.eps = dim, ffn_dim, num_heads, eps
+        self.window_size, self.qk_norm, self.cross_attn_norm = window_size, qk_norm, cross_attn_norm
+        self.self_attn = _Attention(dim, num_heads, eps)
+        self.norm3 = _Affine(dim, eps) if cross_attn_norm else nn.Identity()
+        self.cross_attn = _Attention(dim, num_heads, eps, with_img=with_img)
+        self.ffn = nn.Sequential(nn.Linear(dim, ffn_dim), nn.GELU(approximate="tanh"), nn.Linear(ffn_dim, dim))
+        self.modulation = nn.Parameter(torch.randn(1, 6, dim) / dim ** 0.5)
+
+    def forward(self, *a, **k):
+        raise RuntimeError("WanAttentionBlock is executed by the fused HIP engine via WanModel.forward")
+
+
+class Head(nn.Module):
+    def __init__(self, dim, out_dim, patch_size, eps=1e-6):
+        super().__init__()
+        self.dim, self.out_dim, self.patch_size, self.eps = dim, out_dim, patch_size, eps
+        self.head = nn.Linear(dim, math.prod(patch_size) * out_dim)
+        self.modulation = nn.Parameter(torch.randn(1, 2, dim) / dim ** 0.5)
+
+
+def _pyramid_conv(base: nn.Conv3d, size):
+    """reference model.py:353-366: a (1,k,k)-stride conv whose kernel is the trilinear up-sampling of the base."""
+    oc, ic = base.weight.shape[:2]
+    big = nn.Conv3d(ic, oc, kernel_size=size, stride=size)
+    with torch.no_grad():
+        big.weight.copy_(nn.functional.interpolate(base.weight.detach().float(), size=size, mode="trilinear",
+                                                    align_corners=False))
+        big.bias.copy_(base.bias.detach())
+    return big
+
+
+class WanModel(nn.Module):
+    ignore_for_config = ["patch_size", "cross_attn_norm", "qk_norm", "text_dim", "window_size"]
+    _no_split_modules = ["WanAttentionBlock"]
+    _family = "wan23"
+
+    def __init__(self, model_type="t2v", patch_size=(1, 2, 2), text_len=512, in_dim=16, dim=2048, ffn_dim=8192,
+                 freq_dim=256, text_dim=4096, out_dim=16, num_heads=16, num_layers=32, window_size=(-1, -1),
+                 qk_norm=True, cross_attn_norm=True, eps=1e-6):
+        super().__init__()
+        assert model_type in ("t2v", "i2v", "ti2v")
+        if tuple(patch_size) != (1, 2, 2):
+            raise NotImplementedError("patch_size must be (1, 2, 2)")
+        assert dim % num_heads == 0 and (dim // num_heads) % 2 == 0
+        self.config = dict(model_type=model_type, patch_size=tuple(patch_size), text_len=text_len, in_dim=in_dim,
+                           dim=dim, ffn_dim=ffn_dim, freq_dim=freq_dim, text_dim=text_dim, out_dim=out_dim,
+                           num_heads=num_heads, num_layers=num_layers, window_size=window_size, qk_norm=qk_norm,
+                           cross_attn_norm=cross_attn_norm, eps=eps)
+        for k, v in self.config.items():
+            setattr(self, k, v)
+        self.d = dim // num_heads
+        self.mask_ratio, self.mask_token = 0.3, None
+
+        self.patch_embedding = nn.Conv3d(in_dim, dim, kernel_size=patch_size, stride=patch_size)
+        self.text_embedding = nn.Sequential(nn.Linear(text_dim, dim), nn.GELU(approximate="tanh"), nn.Linear(dim, dim))
+        self.time_embedding = nn.Sequential(nn.Linear(freq_dim, dim), nn.SiLU(), nn.Linear(dim, dim))
+        self.time_projection = nn.Sequential(nn.SiLU(), nn.Linear(dim, dim * 6))
+        self.blocks = nn.ModuleList([
+            WanAttentionBlock(dim, ffn_dim, num_heads, window_size, qk_norm, cross_attn_norm, eps)
+            for _ in range(num_layers)])
+        self.head = Head(dim, out_dim, patch_size, eps)
+        self.init_weights()
+        # pyramid patch embeddings are created in the constructor, like the reference (model.py:486-494)
+        self.patch_embedding_2x = _pyramid_conv(self.patch_embedding, (1, 4, 4))
+        self.patch_embedding_4x = _pyramid_conv(self.patch_embedding, (1, 8, 8))
+        self.patch_embedding_8x = _pyramid_conv(self.patch_embedding, (1, 16, 16))
+        self.patch_embedding_16x = _pyramid_conv(self.patch_embedding, (1, 32, 32))
+        self.patch_embedding_2x_f = nn.Conv3d(in_dim, in_dim, kernel_size=(1, 4, 4), stride=(1, 4, 4))
+        self._engine = None
+
+    # diffusers-style conveniences the drivers touch
+    @property
+    def device(self):
+        return self.patch_embedding.weight.device
+
+    @property
+    def dtype(self):
+        return self.patch_embedding.weight.dtype
+
+    @classmethod
+    def from_config(cls, config, **kw):
+        cfg = {k: v for k, v in dict(config).items() if k in cls.__init__.__code__.co_varnames}
+        cfg.update(kw)
+        return cls(**cfg)
+
+    def init_weights(self):
+        """same distributions as reference model.py:892-914 (xavier Linear, N(0,.02) embeddings, zero head)."""
+        for mod in self.modules():
+            if isinstance(mod, nn.Linear):
+                nn.init.xavier_uniform_(mod.weight)
+                if mod.bias is not None:
+                    nn.init.zeros_(mod.bias)
+        nn.init.xavier_uniform_(self.patch_embedding.weight.flatten(1))
+        for seq in (self.text_embedding, self.time_embedding):
+            for mod in seq.modules():
+                if isinstance(mod, nn.Linear):
+                    nn.init.normal_(mod.weight, std=.02)
+        nn.init.zeros_(self.head.head.weight)
+
+    @property
+    def engine(self):
+        if self._engine is None:
+            self._engine = DiTEngine(self, self._family)
+        return self._engine
+
+    def forward(self, x, t, context, seq_len, enable_mask=False, y=None, latent_frame_zero=8, input_ids=None,
+                flag=True):
+        """x: list of [C_in, F, H, W]; t: [1, seq_len] per-token (flag=True) or [B] / [B, seq_len]; context: list of
+        [L, text_dim]; returns list of fp32 [C_out, F', H, W] — reference model.py:547-865."""
+        if enable_mask:
+            raise NotImplementedError("enable_mask (MDT token masking) is a training-time path, not part of the "
+                                      "inference hot path this implementation covers")
+        if self.model_type == "i2v":
+            assert y is not None
+        if y is not None:
+            x = [torch.cat([u, v], dim=0) for u, v in zip(x, y)]
+        if flag and len(x) != 1:
+            raise NotImplementedError("the FramePack path is single-sample, as in the reference drivers")
+        outs = []
+        for i, u in enumerate(x):
+            if flag:
+                ti = t
+            else:
+                ti = t[i:i + 1] if t.dim() >= 1 and t.shape[0] == len(x) else t
+            outs.append(self.engine.forward_one(u, ti, context[i], packed=bool(flag), lfz=latent_frame_zero))
+        return outs
