@@ -1,0 +1,185 @@
+#!/usr/bin/env python3
+"""bench.py — denoise-steps/sec of the Yume-5B-720P ODE sampler hot loop on N MI355X (one process per GPU).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+           bench.py --gpus N --steps K --warmup W
+
+One "step" = one Euler step of fastvideo/sample/sample_5b.py:960-1034 on BASELINE.json configs[1]: one
+WanModel.forward (no CFG) of the random-init Yume-5B-720P model on a 33-frame 704x1280 clip (latent
+[48,13,44,80], FramePack latent_frame_zero=8, L = 9460 tokens, 512 padded text tokens, per-token timesteps)
+plus the Euler update of the 8 new latent frames. Inputs are resident in HBM before the timed region.
+Multi-GPU: every rank runs its own independent chain (its own prompt/noise), exactly the reference's
+`index = (step-1)*world_size + rank` sharding — no collective inside the loop ("scaling": "weak");
+value = total steps of all ranks / max-over-ranks time.
+
+The JSON line also carries
+  roofline     : the dominant kernel (ffn.0 bf16 MFMA GEMM, 9460x14336x3072) timed with HIP events on the launch
+                 stream inside the timed steps, against the 2.5 PFLOP/s dense bf16 MFMA peak.
+  cpu_baseline : the CPU oracle restatement of the reference (oracle/dit.py) timed on the host cores on a bounded
+                 sample (one DiT block at the full L, extrapolated to 30 blocks), rank 0 / N=1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+MFMA_BF16_PEAK_TFLOPS = 2500.0     # /opt/skills/guides/MI355X_MICROARCH.md: ~2.5 PF dense bf16
+
+
+def flops_fwd_5b(L, C=3072, ffn=14336, n=30, Lc=512, cin=48, cout=48):
+    """SURVEY.md §8(d) F_fwd(L) (2 flop per MAC)."""
+    blk = 8 * L * C * C + 4 * L * L * C + 4 * L * C * C + 4 * Lc * C * C + 4 * L * Lc * C + 4 * L * C * ffn
+    return n * blk + 2 * L * (cin * 4) * C + 2 * 512 * (4096 * C + C * C) + 2 * L * (256 * C + C * C + 6 * C * C) + 2 * L * C * 4 * cout
+
+
+def cpu_baseline(cfg, L, n_hist, seconds_budget=30.0):
+    """Reference restatement on the host cores: one full-width block at the full sequence length."""
+    from oracle import dit as odit
+    from yume_amd import synth
+    torch.set_num_threads(os.cpu_count() or 1)
+    c1 = dict(cfg)
+    c1["num_layers"] = 1
+    sd = {k: v for k, v in synth.make_dit_state_dict(c1, "wan23", seed=0, pyramid=()).items() if k.startswith("blocks.0.")}
+    C = cfg["dim"]
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(L, C, generator=g)
+    e6 = torch.randn(L, 6, C, generator=g) * 0.1
+    ctx = torch.randn(512, C, generator=g)
+    tabs = odit.rope_axes(128)
+    rope = odit.rope_grid(tabs, 1, 1, L, 0) if L <= 1024 else torch.polar(torch.ones(L, 64, dtype=torch.float64),
+                                                                           torch.randn(L, 64, generator=g).double())
+    # fp32 attention for the timing leg (the fp64 exact-softmax of the parity oracle would dominate the CPU time)
+    orig = odit.attention
+
+    def attn32(q, k, v):
+        return torch.nn.functional.scaled_dot_product_attention(q.transpose(0, 1), k.transpose(0, 1), v.transpose(0, 1)).transpose(0, 1)
+    odit.attention = attn32
+    try:
+        t0 = time.time()
+        with torch.no_grad():
+            odit.block_forward(sd, "blocks.0.", x, e6, rope, ctx, c1, "wan23")
+        dt = time.time() - t0
+    finally:
+        odit.attention = orig
+    step_s = dt * cfg["num_layers"]
+    return {"value": 1.0 / step_s, "unit": "denoise-steps/sec", "cores": os.cpu_count(), "kind": "port",
+            "sample": f"1 of {cfg['num_layers']} DiT blocks at L={L} (fp32, {dt:.2f} s), extrapolated x{cfg['num_layers']}; embed/head excluded"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=6)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--layers", type=int, default=0, help="debug only: override num_layers (result is then NOT the named config)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)   # RCCL over xGMI
+
+    import __graft_entry__ as ge
+    if rank == 0:
+        ge.build()
+    if world > 1:
+        dist.barrier()
+    from yume_amd import framepack, synth
+    from yume_amd.wan23.modules.model import WanModel
+
+    cfg = dict(synth.CFG_5B)
+    if args.layers:
+        cfg["num_layers"] = args.layers
+    F, H, W, lfz, steps_total, shift = 13, 44, 80, 8, 50, 7.0
+    with torch.device(dev):
+        model = WanModel(**cfg)
+    synth.randomize_module_(model, seed=0)           # replicated weights: same seed on every rank
+    model = model.to(torch.bfloat16).eval().requires_grad_(False)   # sample_5b.py:1241 casts the transformer to bf16
+    plan = framepack.pack_plan(F, H, W, lfz)
+    L = plan.seq_len
+
+    g = torch.Generator(device=dev).manual_seed(1000 + rank)          # each rank: its own prompt / noise
+    hist = torch.randn((48, F - lfz, H, W), generator=g, device=dev)
+    latent = torch.cat([hist, torch.randn((48, lfz, H, W), generator=g, device=dev)], dim=1)
+    context = [torch.randn((77, 4096), generator=g, device=dev)]
+    sig = synth.sampling_sigmas(steps_total, shift)
+    zeros_hist = torch.zeros(plan.n_hist_tok, dtype=torch.float64, device=dev)
+    ones_new = torch.ones(plan.n_new_tok, dtype=torch.float64, device=dev)
+
+    def step(i, latent):
+        s = sig[i % steps_total]
+        s_next = sig[i % steps_total + 1] if (i % steps_total) + 1 < steps_total else 0.0
+        t = torch.cat([zeros_hist, ones_new * (s * 1000.0)]).unsqueeze(0)              # sample_5b.py:965-972
+        pred = model([latent], t=t, context=context, seq_len=L, latent_frame_zero=lfz, flag=True)[0]
+        new = latent[:, -lfz:] + (s_next - s) * pred                                    # :987-990
+        return torch.cat([hist, new], dim=1)                                            # :1031-1034
+
+    for i in range(args.warmup):
+        latent = step(i, latent)
+    model.engine.prof = []
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.warmup, args.warmup + args.steps):
+        latent = step(i, latent)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    prof, model.engine.prof = model.engine.prof, None
+    assert torch.isfinite(latent).all(), "non-finite latents"
+
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    tmax = float(tmax.item())
+
+    if rank == 0:
+        gemm_ms = sum(a.elapsed_time(b) for a, b in prof) / max(1, len(prof))
+        gemm_flop = 2.0 * L * cfg["ffn_dim"] * cfg["dim"]
+        achieved = gemm_flop / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
+        ms_per_step = tmax / args.steps * 1e3
+        out = {
+            "metric": "denoise-steps/sec (Yume-5B 720P, 33-frame latent)",
+            "value": world * args.steps / tmax, "unit": "denoise-steps/sec",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "Yume-5B-720P random-init, 33-frame 704x1280 clip (latent 48x13x44x80, FramePack "
+                                   "lfz=8, L=9460), ODE Euler steps of a 50-step shift-7 schedule, no CFG, one chain per GPU",
+                       "num_layers": cfg["num_layers"], "tokens": L, "parallelism": f"dp{world} (independent chains, replicated weights)"},
+            "model_tflop_per_step": flops_fwd_5b(L, n=cfg["num_layers"]) / 1e12,
+            "model_tflops_per_gpu": flops_fwd_5b(L, n=cfg["num_layers"]) / 1e12 / (ms_per_step * 1e-3),
+            "roofline": {"bound": "mfma", "kernel": "gemm128_kernel<EPI_BF16_GELU> ffn.0 9460x14336x3072",
+                         "achieved": achieved, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / MFMA_BF16_PEAK_TFLOPS, "traffic": None,
+                         "launch_ms": gemm_ms, "launches_timed": len(prof)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(cfg, L, plan.n_hist_tok)
+            except Exception as e:  # noqa: BLE001 — a baseline failure must not hide the GPU number
+                out["cpu_baseline"] = {"value": None, "unit": "denoise-steps/sec", "cores": os.cpu_count(), "kind": "port",
+                                       "sample": f"failed: {e}"}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

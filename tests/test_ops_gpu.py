@@ -1,0 +1,296 @@
+"""GPU parity of every C-ABI kernel against a plain fp32/fp64 torch restatement of the same op (computed on CPU or
+with torch ops on the device in fp32). Tolerances are stated per test; bf16 outputs are compared after rounding the
+reference to bf16 (|err| <= ~1 bf16 ulp of the value plus accumulation noise)."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from yume_amd import ops  # noqa: E402
+
+DEV = "cuda"
+
+
+def rnd(*shape, seed=0, scale=1.0, dtype=torch.float32):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(dtype)
+
+
+def rel_l2(a, b):
+    return ((a.double() - b.double()).norm() / (b.double().norm() + 1e-30)).item()
+
+
+# ------------------------------------------------------------------------------------------- adaLN
+@pytest.mark.parametrize("T,C,R", [(7, 512, 1), (300, 3072, 2), (65, 5120, 1), (33, 1280, 1)])
+@pytest.mark.parametrize("out_kind", [0, 1, 2])
+def test_adaln_modulate(T, C, R, out_kind):
+    x = rnd(T, C, seed=1) * 3 + 0.5
+    tab = rnd(R, 6, C, seed=2, scale=0.3)
+    idx = (torch.arange(T) % R).to(torch.int32) if R > 1 else None
+    xd, tabd = x.to(DEV), tab.to(DEV)
+    idxd = idx.to(DEV) if idx is not None else None
+    rows = idx.long() if idx is not None else torch.zeros(T, dtype=torch.long)
+    want = torch.nn.functional.layer_norm(x.double(), (C,), eps=1e-6) * (1 + tab[rows, 1].double()) + tab[rows, 0].double()
+    if out_kind == 1:
+        out = torch.empty(T, C, dtype=torch.float32, device=DEV)
+    elif out_kind == 0:
+        out = torch.empty(T, C, dtype=torch.bfloat16, device=DEV)
+    else:
+        out = torch.empty(T, 3 * C, dtype=torch.bfloat16, device=DEV)
+    ops.adaln_modulate(xd, tabd[:, 1], tabd[:, 0], 6 * C, idxd, True, out, out_kind)
+    got = out.cpu()
+    if out_kind == 1:
+        assert (got.double() - want).abs().max() < 2e-5
+    elif out_kind == 0:
+        assert (got.double() - want).abs().max() <= 2.0 ** -8 * want.abs().max()
+    else:
+        hi, hi2, lo = got[:, :C], got[:, C:2 * C], got[:, 2 * C:]
+        assert torch.equal(hi, hi2)
+        assert ((hi.double() + lo.double()) - want).abs().max() < 3e-5 * max(1.0, want.abs().max().item())
+
+
+def test_adaln_affine_mode():
+    T, C = 50, 3072
+    x, w, b = rnd(T, C, seed=3), 1 + 0.1 * rnd(C, seed=4), 0.1 * rnd(C, seed=5)
+    out = torch.empty(T, C, dtype=torch.bfloat16, device=DEV)
+    ops.adaln_modulate(x.to(DEV), w.to(DEV), b.to(DEV), 0, None, False, out, 0)
+    want = torch.nn.functional.layer_norm(x, (C,), w, b, 1e-6)
+    assert (out.cpu().float() - want).abs().max() <= 2.0 ** -8 * want.abs().max()
+
+
+# ------------------------------------------------------------------------------------------- GEMM
+def gemm_ref(a, w, bias):
+    return a.double() @ w.double().t() + (bias.double() if bias is not None else 0)
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 256, 192), (1, 128, 64), (129, 384, 3072), (1000, 192, 1536),
+                                   (257, 512, 1280), (2048, 1024, 512)])
+def test_gemm_bf16_plain_and_f32(M, N, K):
+    a, w, bias = rnd(M, K, seed=1, dtype=torch.bfloat16), rnd(N, K, seed=2, scale=K ** -0.5, dtype=torch.bfloat16), rnd(N, seed=3)
+    want = gemm_ref(a, w, bias)
+    ad, wd, bd = a.to(DEV), w.to(DEV), bias.to(DEV)
+    o32 = torch.empty(M, N, dtype=torch.float32, device=DEV)
+    ops.gemm_bf16(ad, wd, bd, o32, ops.EPI_F32)
+    assert rel_l2(o32.cpu(), want) < 2e-6 * math.sqrt(K) + 1e-6          # fp32 accumulation of exact bf16 products
+    assert (o32.cpu().double() - want).abs().max() < 1e-4 * max(1.0, want.abs().max().item())
+    o16 = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    ops.gemm_bf16(ad, wd, bd, o16, ops.EPI_BF16)
+    assert (o16.cpu().double() - want).abs().max() <= 2.0 ** -8 * want.abs().max() + 1e-6
+    og = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    ops.gemm_bf16(ad, wd, bd, og, ops.EPI_BF16_GELU)
+    wg = torch.nn.functional.gelu(want, approximate="tanh")
+    assert (og.cpu().double() - wg).abs().max() <= 2.0 ** -7 * wg.abs().max() + 1e-5
+    oe = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    ops.gemm_bf16(ad, wd, bd, oe, ops.EPI_BF16_GELU_ERF)
+    we = torch.nn.functional.gelu(want)
+    assert (oe.cpu().double() - we).abs().max() <= 2.0 ** -7 * we.abs().max() + 1e-5
+
+
+def test_gemm_detects_transpose_and_permutation():
+    """A = I-like and asymmetric W: a swapped row/col in the C-write or a k-permutation mismatch cannot pass."""
+    M, N, K = 256, 256, 256
+    a = torch.eye(M, K)
+    w = (torch.arange(N).view(N, 1) * 3 + torch.arange(K).view(1, K) % 7).float() / 64
+    o = torch.empty(M, N, dtype=torch.float32, device=DEV)
+    ops.gemm_bf16(a.to(torch.bfloat16).to(DEV), w.to(torch.bfloat16).to(DEV), None, o, ops.EPI_F32)
+    assert torch.equal(o.cpu(), w.to(torch.bfloat16).float().t().contiguous())
+
+
+@pytest.mark.parametrize("M,N,K,R", [(300, 512, 512, 2), (130, 3072, 1024, 1)])
+def test_gemm_resid_gate(M, N, K, R):
+    a, w, bias = rnd(M, K, seed=1, dtype=torch.bfloat16), rnd(N, K, seed=2, scale=K ** -0.5, dtype=torch.bfloat16), rnd(N, seed=3)
+    x = rnd(M, N, seed=4)
+    tab = rnd(R, 6, N, seed=5)
+    idx = (torch.arange(M) % R).to(torch.int32)
+    xd = x.to(DEV).clone()
+    tabd = tab.to(DEV)
+    ops.gemm_bf16(a.to(DEV), w.to(DEV), bias.to(DEV), xd, ops.EPI_RESID, gate=tabd[:, 2], gate_stride=6 * N,
+                  row_idx=idx.to(DEV) if R > 1 else None)
+    want = x.double() + gemm_ref(a, w, bias) * tab[idx.long() if R > 1 else torch.zeros(M, dtype=torch.long), 2].double()
+    assert (xd.cpu().double() - want).abs().max() < 1e-4 * max(1.0, want.abs().max().item())
+    xd2 = x.to(DEV).clone()
+    ops.gemm_bf16(a.to(DEV), w.to(DEV), bias.to(DEV), xd2, ops.EPI_RESID)
+    assert (xd2.cpu().double() - (x.double() + gemm_ref(a, w, bias))).abs().max() < 1e-4 * max(1.0, want.abs().max().item())
+
+
+@pytest.mark.parametrize("M", [64, 301, 516])
+def test_gemm_split_transposed(M):
+    C, K = 256, 512
+    N = 3 * C
+    a, w, bias = rnd(M, K, seed=1, dtype=torch.bfloat16), rnd(N, K, seed=2, scale=K ** -0.5, dtype=torch.bfloat16), rnd(N, seed=3)
+    want = gemm_ref(a, w, bias)
+    Mp = (M + 7) // 8 * 8
+    qk = torch.empty(M, 2 * C, dtype=torch.bfloat16, device=DEV)
+    vt = torch.zeros(C, Mp, dtype=torch.bfloat16, device=DEV)
+    ops.gemm_bf16(a.to(DEV), w.to(DEV), bias.to(DEV), qk, ops.EPI_BF16_SPLITT, out_t=vt, n_split=2 * C)
+    tol = 2.0 ** -8 * want.abs().max() + 1e-6
+    assert (qk.cpu().double() - want[:, :2 * C]).abs().max() <= tol
+    assert (vt.cpu()[:, :M].double() - want[:, 2 * C:].t()).abs().max() <= tol
+    assert (vt.cpu()[:, M:] == 0).all()      # padding columns untouched
+
+
+# ------------------------------------------------------------------------------------------- RMSNorm + RoPE
+@pytest.mark.parametrize("T,C,nparts,rope", [(100, 512, 2, True), (37, 3072, 2, True), (64, 5120, 2, True), (50, 3072, 1, False)])
+def test_rmsnorm_rope(T, C, nparts, rope):
+    ld = nparts * C + 64
+    buf = rnd(T, ld, seed=1, dtype=torch.bfloat16)
+    w = 1 + 0.1 * rnd(nparts, C, seed=2)
+    ang = rnd(T, 64, seed=3) * 3
+    cs = torch.stack([torch.cos(ang.double()), torch.sin(ang.double())], dim=-1).float()
+    bd = buf.to(DEV).clone()
+    ops.rmsnorm_rope(bd, C, nparts, w.to(DEV), 1e-6, cs.to(DEV) if rope else None)
+    got = bd.cpu()
+    assert torch.equal(got[:, nparts * C:], buf[:, nparts * C:])          # columns beyond the parts untouched
+    for p in range(nparts):
+        x = buf[:, p * C:(p + 1) * C].double()
+        y = x * torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + 1e-6) * w[p].double()
+        if rope:
+            yc = torch.view_as_complex(y.reshape(T, C // 128, 64, 2).contiguous())
+            y = torch.view_as_real(yc * torch.polar(torch.ones_like(ang.double()), ang.double()).unsqueeze(1)).reshape(T, C)
+        err = (got[:, p * C:(p + 1) * C].double() - y).abs().max()
+        assert err <= 2.0 ** -8 * y.abs().max() + 1e-6, (p, err)
+
+
+# ------------------------------------------------------------------------------------------- attention
+def attn_ref(q, k, v, scale):
+    qd, kd, vd = (t.double().transpose(0, 1) for t in (q, k, v))      # [H, L, D]
+    a = torch.softmax(qd @ kd.transpose(1, 2) * scale, dim=-1)
+    return (a @ vd).transpose(0, 1)                                     # [Lq, H, D]
+
+
+def run_attn(q, k, v, scale=None, accumulate=None):
+    Lq, H, D = q.shape
+    Lk = k.shape[0]
+    vt = torch.empty(H * D, (Lk + 7) // 8 * 8, dtype=torch.bfloat16, device=DEV).fill_(float("nan"))
+    ops.transpose_bf16(v.reshape(Lk, H * D).to(DEV), vt)
+    out = torch.empty(Lq, H * D, dtype=torch.bfloat16, device=DEV) if accumulate is None else accumulate
+    ops.attn_fwd(q.reshape(Lq, H * D).to(DEV), k.reshape(Lk, H * D).to(DEV), vt, out, Lq, Lk, H, scale=scale,
+                 accumulate=accumulate is not None)
+    return out.cpu().view(Lq, H, D)
+
+
+@pytest.mark.parametrize("Lq,Lk,H", [(128, 64, 1), (32, 128, 2), (300, 300, 3), (1000, 512, 4), (517, 257, 2), (2048, 2048, 8),
+                                     (64, 1, 1), (1, 77, 3), (130, 1000, 24)])
+def test_attention_matches_exact_softmax(Lq, Lk, H):
+    q, k, v = (rnd(L, H, 128, seed=s, dtype=torch.bfloat16) for L, s in ((Lq, 1), (Lk, 2), (Lk, 3)))
+    want = attn_ref(q, k, v, 1 / math.sqrt(128))
+    got = run_attn(q, k, v)
+    assert torch.isfinite(got).all()
+    # P is rounded to bf16 before PV (as flash-attn does): max-abs 2^-7 of the value scale, rel-L2 well below bf16 eps
+    assert (got.double() - want).abs().max() <= 1.5e-2 * max(want.abs().max().item(), 1e-3)
+    assert rel_l2(got, want) < 6e-3
+
+
+def test_attention_rescale_branch_and_scale():
+    """a key that spikes late forces the running max to jump (online-softmax rescale) in a chosen tile."""
+    Lq, Lk, H = 96, 640, 2
+    q, k, v = (rnd(L, H, 128, seed=s, dtype=torch.bfloat16) for L, s in ((Lq, 4), (Lk, 5), (Lk, 6)))
+    k[411] = (q[17].float() * 6).to(torch.bfloat16)      # huge score for query 17 in tile 6
+    k[5] = (q[40].float() * 3).to(torch.bfloat16)
+    for scale in (1 / math.sqrt(128), 0.3):
+        want = attn_ref(q, k, v, scale)
+        got = run_attn(q, k, v, scale=scale)
+        assert (got.double() - want).abs().max() <= 2e-2 * want.abs().max()
+
+
+def test_attention_accumulate_and_transposed_operand():
+    Lq, Lk, H = 200, 257, 2
+    q, k, v = (rnd(L, H, 128, seed=s, dtype=torch.bfloat16) for L, s in ((Lq, 7), (Lk, 8), (Lk, 9)))
+    base = rnd(Lq, H * 128, seed=10, dtype=torch.bfloat16)
+    got = run_attn(q, k, v, accumulate=base.to(DEV).clone())
+    want = attn_ref(q, k, v, 1 / math.sqrt(128)) + base.view(Lq, H, 128).double()
+    assert (got.double() - want).abs().max() <= 2e-2 * want.abs().max()
+    # asymmetric V (value = its own key index in d=0, head index in d=1) catches key/head permutations
+    v2 = torch.zeros(Lk, H, 128)
+    v2[:, :, 0] = torch.arange(Lk).view(Lk, 1) / 64.0
+    v2[:, :, 1] = torch.arange(H).view(1, H) + 1.0
+    v2 = v2.to(torch.bfloat16)
+    got = run_attn(q, k, v2)
+    want = attn_ref(q, k, v2, 1 / math.sqrt(128))
+    assert (got.double() - want).abs().max() <= 2e-2 * want.abs().max()
+
+
+def test_flash_attention_seam():
+    from yume_amd.attention import flash_attention
+    B, Lq, Lk, H = 2, 150, 90, 3
+    q, k, v = rnd(B, Lq, H, 128, seed=1), rnd(B, Lk, H, 128, seed=2), rnd(B, Lk, H, 128, seed=3)
+    out = flash_attention(q.to(DEV), k.to(DEV), v.to(DEV), k_lens=torch.tensor([90, 61]))
+    assert out.dtype == torch.float32 and out.shape == (B, Lq, H, 128)
+    for b, lk in ((0, 90), (1, 61)):
+        want = attn_ref(q[b].bfloat16(), k[b, :lk].bfloat16(), v[b, :lk].bfloat16(), 1 / math.sqrt(128))
+        assert (out[b].cpu().double() - want).abs().max() <= 2e-2 * want.abs().max()
+
+
+# ------------------------------------------------------------------------------------------- small helpers
+def test_sinusoidal_and_time_mlp():
+    t = torch.tensor([0.0, 731.4285714285714, 1000.0, 3.25], dtype=torch.float64)
+    idx = torch.tensor([3, 0, 1], dtype=torch.int32)
+    out = torch.empty(3, 256, dtype=torch.float32, device=DEV)
+    ops.sinusoidal_embed(t.to(DEV), idx.to(DEV), 3, 256, out)
+    half = 128
+    w = torch.pow(10000.0, -torch.arange(half, dtype=torch.float64) / half)
+    a = torch.outer(t[idx.long()], w)
+    want = torch.cat([torch.cos(a), torch.sin(a)], dim=1).float()
+    assert (out.cpu() - want).abs().max() < 1e-6
+    for wd in (torch.float32, torch.bfloat16):
+        R, K, N = 3, 256, 520
+        x, W, b, add = rnd(R, K, seed=1), rnd(N, K, seed=2, scale=0.05).to(wd), rnd(N, seed=3), rnd(N, seed=4)
+        o = torch.empty(R, N, dtype=torch.float32, device=DEV)
+        ops.linear_smallm_f32(x.to(DEV), W.to(DEV), b.to(DEV), o, in_act=1, out_act=1, add_table=add.to(DEV))
+        want = torch.nn.functional.silu(torch.nn.functional.silu(x.double()) @ W.double().t() + b.double()) + add.double()
+        assert (o.cpu().double() - want).abs().max() < 1e-5
+
+
+def test_modulation_table():
+    tab, e0 = rnd(5, 48, seed=1), rnd(3, 48, seed=2)
+    out = torch.empty(5, 3, 48, device=DEV)
+    ops.modulation_table(tab.to(DEV), e0.to(DEV), out)
+    assert torch.equal(out.cpu(), tab[:, None, :] + e0[None, :, :])
+
+
+@pytest.mark.parametrize("k,dtype", [(2, torch.float32), (4, torch.float32), (8, torch.bfloat16), (32, torch.float32)])
+def test_patch_gather_matches_conv3d(k, dtype):
+    Cin, F, H, W, Co = 6, 5, 11, 14, 8
+    x = rnd(Cin, F, H, W, seed=1).to(dtype)
+    wt = rnd(Co, Cin, 1, k, k, seed=2)
+    f0, nf = 1, 3
+    Hp, Wp = -(-H // k), -(-W // k)
+    K = Cin * k * k
+    Kp = (K + 63) // 64 * 64
+    out = torch.empty(nf * Hp * Wp, Kp, dtype=torch.bfloat16, device=DEV)
+    ops.patch_gather(x.to(DEV), f0, nf, k, k, out)
+    xp = torch.nn.functional.pad(x[:, f0:f0 + nf].float(), (0, Wp * k - W, 0, Hp * k - H)).to(torch.bfloat16).float()
+    want = torch.nn.functional.conv3d(xp.unsqueeze(0), wt, stride=(1, k, k))[0].flatten(1).t()
+    got = out.cpu().float()[:, :K] @ wt.flatten(1).t()
+    assert (got - want).abs().max() < 1e-3
+    assert (out.cpu()[:, K:] == 0).all()
+
+
+def test_unpatchify_cast_transpose():
+    Fr, Hp, Wp, Co = 3, 4, 5, 6
+    y = rnd(Fr * Hp * Wp, 4 * Co, seed=1)
+    out = torch.empty(Co, Fr, 2 * Hp, 2 * Wp, device=DEV)
+    ops.unpatchify(y.to(DEV), Fr, Hp, Wp, 2, 2, Co, out)
+    want = torch.einsum("fhwpqrc->cfphqwr", y.view(Fr, Hp, Wp, 1, 2, 2, Co)).reshape(Co, Fr, 2 * Hp, 2 * Wp)
+    assert torch.equal(out.cpu(), want)
+    x = rnd(5, 64, seed=2)
+    o = torch.empty(9, 64, dtype=torch.bfloat16, device=DEV)
+    ops.cast_bf16(x.to(DEV), 5, o)
+    assert torch.equal(o.cpu()[:5], x.to(torch.bfloat16)) and (o.cpu()[5:] == 0).all()
+    for dt in (torch.float32, torch.bfloat16):
+        z = rnd(70, 45, seed=3).to(dt)
+        ot = torch.zeros(45, 72, dtype=torch.bfloat16, device=DEV)
+        ops.transpose_bf16(z.to(DEV), ot)
+        assert torch.equal(ot.cpu()[:, :70], z.to(torch.bfloat16).t())
+
+
+def test_errors_are_loud():
+    a = torch.zeros(4, 60, dtype=torch.bfloat16, device=DEV)
+    w = torch.zeros(8, 60, dtype=torch.bfloat16, device=DEV)
+    o = torch.zeros(4, 8, dtype=torch.bfloat16, device=DEV)
+    with pytest.raises(RuntimeError, match="multiple"):
+        ops.gemm_bf16(a, w, None, o)
+    with pytest.raises(RuntimeError, match="device"):
+        ops.gemm_bf16(a.cpu(), w, None, o)

@@ -141,3 +141,33 @@ def sampling_sigmas(steps, shift):
     """fastvideo/sample/sample_5b.py:502-506 get_sampling_sigmas."""
     s = torch.linspace(1, 0, steps + 1, dtype=torch.float64)[:steps]
     return (shift * s / (1 + (shift - 1) * s)).tolist()
+
+
+@torch.no_grad()
+def randomize_module_(model, seed=0):
+    """Fill every parameter of a (device-resident) WanModel in place with the same per-key scale rules as
+    make_tensor, using the parameter's own device generator (fast path for full-size bench models; values differ
+    from the CPU generator's)."""
+    dev = next(model.parameters()).device
+    g = torch.Generator(device=dev)
+    dim = model.dim
+    for key, p in model.named_parameters():
+        g.manual_seed((seed * 1000003 + zlib.crc32(key.encode())) & 0x7FFFFFFF)
+        leaf = key.split(".")[-1]
+        shape = tuple(p.shape)
+        if leaf == "modulation":
+            v = torch.randn(shape, generator=g, device=dev) / math.sqrt(dim)
+        elif "norm" in key or key.startswith(("img_emb.proj.0", "img_emb.proj.4")):
+            v = torch.randn(shape, generator=g, device=dev) * (0.1 if leaf == "weight" else 0.05) + (1.0 if leaf == "weight" else 0.0)
+        elif leaf == "bias":
+            v = torch.randn(shape, generator=g, device=dev) * 0.02
+        elif key.startswith(("text_embedding", "time_embedding", "head.head")):
+            v = torch.randn(shape, generator=g, device=dev) * 0.02
+        else:
+            fan_in = 1
+            for s in shape[1:]:
+                fan_in *= s
+            a = math.sqrt(6.0 / (fan_in + shape[0]))
+            v = (torch.rand(shape, generator=g, device=dev) * 2 - 1) * a
+        p.copy_(v.to(p.dtype))
+    return model
