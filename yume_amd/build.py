@@ -35,7 +35,7 @@ def _fingerprint():
     files = sorted([os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(INCLUDE, "yume_hip.h")])
     for f in files:
         if os.path.isfile(f):
-            h.update(f.encode())
+            h.update(os.path.basename(f).encode())   # content-addressed: the tree may live at another path (GPU box)
             with open(f, "rb") as fh:
                 h.update(fh.read())
     h.update(" ".join(FLAGS).encode())
