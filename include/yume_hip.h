@@ -181,6 +181,79 @@ int yume_cast_bf16(const float* in, int64_t ldi, int64_t rows_valid, int64_t row
 int yume_transpose_bf16(const void* in, int in_bf16, int64_t ldi, int64_t rows, int64_t cols,
                         void* out, int64_t ldo, void* stream);
 
+/* ======================================================================================================
+ * Causal 3D VAE (Wan2.2 z=48 stride 4x16x16 and Wan2.1 z=16 stride 4x8x8).
+ * Activations are bf16 CHANNELS-LAST [T, H, W, C] (row = one (t,h,w) position, `ldc` elements apart, C % 8 == 0);
+ * the reference layout fp32 [C, T, H, W] only exists at the two ends (yume_vae_pack_input / yume_vae_unpack_output).
+ * ====================================================================================================== */
+
+/* ---- implicit-GEMM convolution -------------------------------------------------------------------------
+ * replaces: wan23/modules/vae2_2.py:17-44 CausalConv3d (3x3x3, (3,1,1), 1x1x1; the 2-frame feat_cache is the
+ *           `cache` operand instead of torch.cat + F.pad), :88-98 Upsample(nearest-exact x2)+Conv2d 3x3 (ups=1),
+ *           :101-110 ZeroPad2d((0,1,0,1))+Conv2d 3x3 stride 2 and the stride-(2,1,1) time_conv; same classes in
+ *           wan/modules/vae.py.
+ *   out[(to,ho,wo), co] = bias[co] + sum_{dt,dh,dw,ci} in(ti,hi,wi)[ci] * W[co, ((dt*kh+dh)*kw+dw)*Cin + ci]
+ *   ti = to*st + dt - pt: ti < 0 reads cache frame 2+ti (cache = the last two input frames of the previous
+ *   chunk, [2,Hin,Win,ldc]) or zeros when cache is NULL; hi = ho*sh + dh - ph, wi likewise, zero outside the frame;
+ *   ups != 0: (hi, wi) index a nearest-2x-upsampled view of the input (hi>>1, wi>>1).
+ * W: bf16 [Cout, ldw], ldw >= kt*kh*kw*Cin rounded up to 64, zero padded. zero_page: >= 16 zero bytes on the device.
+ * epi: YUME_EPI_BF16 (bias), YUME_EPI_F32, YUME_CONV_EPI_ADD (out = acc + bias + add[m, co], add bf16 [M, ldadd] —
+ *      the ResidualBlock skip, vae2_2.py:239), YUME_CONV_EPI_TSPLIT (upsample3d time_conv, vae2_2.py:145-153:
+ *      channel halves of frame t become frames 2t and 2t+1: out[((2t+j)*Ho*Wo + hw), c] for co = j*Cout/2 + c).
+ */
+enum { YUME_CONV_EPI_ADD = 16, YUME_CONV_EPI_TSPLIT = 17 };
+int yume_conv3d_cl(const void* x, const void* cache, int64_t ldc, int64_t Tin, int64_t Hin, int64_t Win, int64_t Cin,
+                   const void* W, int64_t ldw, const float* bias, int64_t Cout,
+                   int kt, int kh, int kw, int st, int sh, int sw, int pt, int ph, int pw, int ups,
+                   int64_t To, int64_t Ho, int64_t Wo, int epi, void* out, int64_t ldo,
+                   const void* add, int64_t ldadd, const void* zero_page, void* stream);
+
+/* ---- RMS_norm (+SiLU) over channels ---------------------------------------------------------------------
+ * replaces: vae2_2.py:47-61 RMS_norm = F.normalize(x, dim=channel) * sqrt(C) * gamma (+ bias), followed by nn.SiLU
+ *           in ResidualBlock (:204-208) and the heads (:560-561,676-677).
+ *   y[m, c] = act( x[m, c] / max(||x[m, :]||_2, 1e-12) * sqrt(C) * gamma[c] + beta[c] ),  act = SiLU if silu != 0
+ * x, y: bf16 [M, C] (ldx, ldy); gamma fp32 [C]; beta fp32 [C] or NULL. fp32 statistics. C % 8 == 0, C <= 4096.
+ */
+int yume_vae_rmsnorm_silu(const void* x, int64_t ldx, int64_t M, int64_t C, const float* gamma, const float* beta,
+                          int silu, void* y, int64_t ldy, void* stream);
+
+/* ---- DupUp3D shortcut, added in place --------------------------------------------------------------------
+ * replaces: vae2_2.py:376-418 DupUp3D + the `x_main + x_shortcut` of Up_ResidualBlock (:499-501).
+ *   y[(t', h', w'), oc] += x[(t'+toff)/ft, h'/fs, w'/fs][ (oc*ft*fs*fs + a*fs*fs + b*fs + c) / repeats ]
+ *   a = (t'+toff)%ft, b = h'%fs, c = w'%fs, repeats = Cout*ft*fs*fs/Cin; toff = ft-1 on the first chunk (the
+ *   reference drops the first ft-1 duplicated frames there), else 0.
+ * x bf16 [Tin,Hin,Win,Cin] (ldx); y bf16 [To, Hin*fs, Win*fs, Cout] (ldy), in/out.
+ */
+int yume_vae_dupup_add(const void* x, int64_t ldx, int64_t Tin, int64_t Hin, int64_t Win, int64_t Cin,
+                       void* y, int64_t ldy, int64_t To, int64_t Cout, int ft, int fs, int toff, void* stream);
+
+/* ---- AvgDown3D shortcut, added in place --------------------------------------------------------------------
+ * replaces: vae2_2.py:322-373 AvgDown3D + the `x + avg_shortcut(x_copy)` of Down_ResidualBlock (:458).
+ *   y[(t,h,w), oc] += mean_{g < G} x'[oc*G + g],  x'[ci*ft*fs*fs + a*fs*fs + b*fs + c] = x[(t*ft + a - padt, h*fs+b, w*fs+c), ci]
+ *   G = Cin*ft*fs*fs/Cout; padt = (ft - Tin%ft)%ft zero frames in FRONT (frames with index < 0 contribute 0).
+ */
+int yume_vae_avgdown_add(const void* x, int64_t ldx, int64_t Tin, int64_t Hin, int64_t Win, int64_t Cin,
+                         void* y, int64_t ldy, int64_t Cout, int ft, int fs, void* stream);
+
+/* ---- row softmax for the single-head VAE attention -----------------------------------------------------------
+ * replaces: the softmax inside F.scaled_dot_product_attention of AttentionBlock (vae2_2.py:272-276); the two
+ *           matmuls around it run on yume_gemm_bf16.  P[r, :n] = softmax(scale * S[r, :n]) (bf16), P[r, n:ldp] = 0.
+ */
+int yume_softmax_rows(const float* S, int64_t lds, int64_t R, int64_t n, float scale, void* P, int64_t ldp, void* stream);
+
+/* ---- layout conversion at the two ends of the VAE --------------------------------------------------------------
+ * yume_vae_pack_input: fp32|bf16 [C, T, H, W] -> bf16 channels-last [T, H/ps, W/ps, Cpad] with
+ *   v = x[c] * mul[c] + add[c] (mul/add fp32 [C] or NULL: the `z/scale[1] + scale[0]` of decode, vae2_2.py:833-838)
+ *   and, for ps = 2, patchify "b c f (h q) (w r) -> b (c r q) f h w" (vae2_2.py:286-302); channels >= C*ps*ps are 0.
+ * yume_vae_unpack_output: bf16 channels-last [T, H, W, ldx] (first Cv channels) -> fp32 [Cv/(ps*ps), T, H*ps, W*ps]
+ *   with unpatchify (vae2_2.py:305-319), v = (x - sub[c]) * mul[c] (encode's `(mu - mean) * (1/std)`, :821-826)
+ *   and clamp to [lo, hi] when lo < hi (decode's .clamp_(-1, 1), :1066).
+ */
+int yume_vae_pack_input(const void* x, int in_bf16, int64_t C, int64_t T, int64_t H, int64_t W, int ps,
+                        const float* mul, const float* add, void* out, int64_t Cpad, void* stream);
+int yume_vae_unpack_output(const void* x, int64_t ldx, int64_t T, int64_t H, int64_t W, int64_t Cv, int ps,
+                           const float* sub, const float* mul, float lo, float hi, float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -28,6 +28,14 @@ SIGNATURES = {
     "yume_unpatchify": [_P, _L, _L, _L, _L, _L, _L, _L, _P, _P],
     "yume_cast_bf16": [_P, _L, _L, _L, _L, _P, _L, _P],
     "yume_transpose_bf16": [_P, _I, _L, _L, _L, _P, _L, _P],
+    "yume_conv3d_cl": [_P, _P, _L, _L, _L, _L, _L, _P, _L, _P, _L, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _L, _L, _L, _I, _P, _L,
+                       _P, _L, _P, _P],
+    "yume_vae_rmsnorm_silu": [_P, _L, _L, _L, _P, _P, _I, _P, _L, _P],
+    "yume_vae_dupup_add": [_P, _L, _L, _L, _L, _L, _P, _L, _L, _L, _I, _I, _I, _P],
+    "yume_vae_avgdown_add": [_P, _L, _L, _L, _L, _L, _P, _L, _L, _I, _I, _P],
+    "yume_softmax_rows": [_P, _L, _L, _L, _F, _P, _L, _P],
+    "yume_vae_pack_input": [_P, _I, _L, _L, _L, _L, _I, _P, _P, _P, _L, _P],
+    "yume_vae_unpack_output": [_P, _L, _L, _L, _L, _L, _I, _P, _P, _F, _F, _P, _P],
 }
 _RES = {"yume_last_error": c_char_p, "yume_target_arch": c_char_p}
 

@@ -1,0 +1,137 @@
+// conv3d.hip — implicit-GEMM convolutions of the causal 3D VAE on channels-last bf16 activations (gfx950).
+//
+//   out[(to,ho,wo), co] = bias[co] + sum_{dt,dh,dw,ci} in[(ti,hi,wi), ci] * W[co, ((dt*kh+dh)*kw+dw)*Cin + ci]
+//   ti = to*st + dt - pt   (ti < 0 reads the 2-frame causal cache: frame 2+ti, or zeros without a cache)
+//   hi = ho*sh + dh - ph , wi = wo*sw + dw - pw   (outside the frame -> 0); with `ups` the spatial gather
+//   addresses a nearest-2x-upsampled view of the input (hi>>1, wi>>1), folding nn.Upsample into the conv.
+//
+// This is gemm_core's pipeline with M = To*Ho*Wo, N = Cout, K = kt*kh*kw*Cin (padded to 64) and an A loader that
+// computes, per 16-byte chunk (8 channels), the address of the tap it belongs to; out-of-image / padded taps
+// are fetched from a caller-provided zero page so the LDS-DMA stays unconditional.
+// One kernel covers every conv in the VAE: CausalConv3d 3x3x3 and (3,1,1) (with/without temporal stride 2),
+// Conv2d 3x3 after nearest-exact x2, Conv2d 3x3 stride 2 after ZeroPad2d((0,1,0,1)), and 1x1x1.
+// Roofline: MFMA (bf16 dense); algorithmic work 2*M*Cout*Cin*kt*kh*kw flop per launch.
+#include "gemm_core.hpp"
+
+using namespace gemm_core;
+
+namespace {
+
+struct ConvA {
+    const unsigned short* x;       // [Tin, Hin, Win, ldc]
+    const unsigned short* cache;   // [2, Hin, Win, ldc] or nullptr
+    const unsigned short* zero;    // >= 16 bytes of zeros
+    int64_t ldc;
+    int Tin, Hin, Win, Cin;
+    int To, Ho, Wo, M;
+    int kt, kh, kw, st, sh, sw, pt, ph, pw, ups;
+    // per-thread state
+    int t0[4], h0[4], w0[4];
+    int cin, dt, dh, dw;
+
+    __device__ __forceinline__ void init(int m0, int tid) {
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            int m = m0 + rr * 32 + (tid >> 3);
+            m = m < M ? m : M - 1;
+            const int wo = m % Wo;
+            const int ho = (m / Wo) % Ho;
+            const int to = m / (Wo * Ho);
+            t0[rr] = to * st - pt;
+            h0[rr] = ho * sh - ph;
+            w0[rr] = wo * sw - pw;
+        }
+        const int lc = (tid & 7) ^ ((tid >> 3) & 7);   // logical 16-byte chunk of this thread (same for its 4 rows)
+        const int k = lc * 8;
+        int tap = k / Cin;
+        cin = k - tap * Cin;
+        dw = tap % kw;
+        dh = (tap / kw) % kh;
+        dt = tap / (kw * kh);
+    }
+    __device__ __forceinline__ const unsigned short* src(int rr, int /*kt_unused*/) const {
+        const int ti = t0[rr] + dt;
+        int hi = h0[rr] + dh, wi = w0[rr] + dw;
+        bool ok = dt < kt;
+        if (ups) {
+            ok = ok && hi >= 0 && hi < 2 * Hin && wi >= 0 && wi < 2 * Win;
+            hi >>= 1;
+            wi >>= 1;
+        } else {
+            ok = ok && hi >= 0 && hi < Hin && wi >= 0 && wi < Win;
+        }
+        const unsigned short* base = x;
+        int tf = ti;
+        if (ti < 0) {
+            base = cache;
+            tf = ti + 2;
+            ok = ok && cache != nullptr && tf >= 0;
+        }
+        if (!ok) return zero;
+        const int64_t pos = ((int64_t)tf * Hin + hi) * Win + wi;
+        return base + pos * ldc + cin;
+    }
+    __device__ __forceinline__ void advance() {
+        cin += BK;
+        while (cin >= Cin) {
+            cin -= Cin;
+            if (++dw == kw) {
+                dw = 0;
+                if (++dh == kh) { dh = 0; ++dt; }
+            }
+        }
+    }
+};
+
+}  // namespace
+
+extern "C" int yume_conv3d_cl(const void* x, const void* cache, int64_t ldc, int64_t Tin, int64_t Hin, int64_t Win,
+                              int64_t Cin, const void* W, int64_t ldw, const float* bias, int64_t Cout, int kt, int kh,
+                              int kw, int st, int sh, int sw, int pt, int ph, int pw, int ups, int64_t To, int64_t Ho,
+                              int64_t Wo, int epi, void* out, int64_t ldo, const void* add, int64_t ldadd,
+                              const void* zero_page, void* stream) {
+    YUME_REQUIRE(x && W && out && zero_page, "conv3d_cl: NULL pointer");
+    YUME_REQUIRE(Tin > 0 && Hin > 0 && Win > 0 && Cin > 0 && Cout > 0 && To > 0 && Ho > 0 && Wo > 0, "conv3d_cl: empty shape");
+    YUME_REQUIRE((Cin % 8) == 0 && (ldc % 8) == 0 && ldc >= Cin, "conv3d_cl: Cin=%lld and ldc=%lld must be multiples of 8", (long long)Cin, (long long)ldc);
+    YUME_REQUIRE((Cout % 4) == 0 && (ldo % 4) == 0, "conv3d_cl: Cout and ldo must be multiples of 4");
+    YUME_REQUIRE(kt >= 1 && kh >= 1 && kw >= 1 && st >= 1 && sh >= 1 && sw >= 1 && pt >= 0 && pt <= 2, "conv3d_cl: bad kernel geometry");
+    const int64_t Ktrue = (int64_t)kt * kh * kw * Cin;
+    const int64_t Kp = (Ktrue + BK - 1) / BK * BK;
+    YUME_REQUIRE(ldw >= Kp && (ldw % 8) == 0, "conv3d_cl: weight rows must hold K padded to 64 (%lld), ldw=%lld", (long long)Kp, (long long)ldw);
+    // the last input frame/row/col a valid tap may touch must exist
+    YUME_REQUIRE((To - 1) * st + (kt - 1) - pt < Tin, "conv3d_cl: temporal extent exceeds the input (To=%lld Tin=%lld)", (long long)To, (long long)Tin);
+    const int64_t M = To * Ho * Wo;
+    YUME_REQUIRE(M < (1ll << 31), "conv3d_cl: too many output positions");
+    YUME_REQUIRE(((uintptr_t)x % 16) == 0 && ((uintptr_t)W % 16) == 0 && ((uintptr_t)out % 8) == 0 && ((uintptr_t)zero_page % 16) == 0 &&
+                 (cache == nullptr || ((uintptr_t)cache % 16) == 0), "conv3d_cl: pointer alignment");
+    Problem p;
+    p.W = (const unsigned short*)W; p.ldw = ldw;
+    p.M = (int)M; p.N = (int)Cout; p.K = (int)Kp;
+    p.tiles_m = (int)((M + BM - 1) / BM);
+    p.tiles_n = (int)((Cout + BN - 1) / BN);
+    ConvA al = {};
+    al.x = (const unsigned short*)x; al.cache = (const unsigned short*)cache; al.zero = (const unsigned short*)zero_page;
+    al.ldc = ldc;
+    al.Tin = (int)Tin; al.Hin = (int)Hin; al.Win = (int)Win; al.Cin = (int)Cin;
+    al.To = (int)To; al.Ho = (int)Ho; al.Wo = (int)Wo; al.M = (int)M;
+    al.kt = kt; al.kh = kh; al.kw = kw; al.st = st; al.sh = sh; al.sw = sw; al.pt = pt; al.ph = ph; al.pw = pw; al.ups = ups;
+    Epilogue e = {};
+    e.bias = bias;
+    e.out = out; e.ldo = ldo;
+    e.add = (const unsigned short*)add; e.ldadd = ldadd;
+    e.hw = (int)(Ho * Wo);
+    hipStream_t s = (hipStream_t)stream;
+    switch (epi) {
+        case YUME_EPI_BF16: return launch<YUME_EPI_BF16>(p, al, e, s, "conv3d_cl");
+        case YUME_EPI_F32: return launch<YUME_EPI_F32>(p, al, e, s, "conv3d_cl");
+        case YUME_CONV_EPI_ADD:
+            YUME_REQUIRE(add != nullptr && (ldadd % 4) == 0, "conv3d_cl: ADD epilogue needs an addend with ldadd %% 4 == 0");
+            return launch<EPI_BF16_ADD>(p, al, e, s, "conv3d_cl");
+        case YUME_CONV_EPI_TSPLIT:
+            YUME_REQUIRE((Cout % 8) == 0, "conv3d_cl: TSPLIT needs an even channel split");
+            return launch<EPI_BF16_TSPLIT>(p, al, e, s, "conv3d_cl");
+        default:
+            yume_set_error("conv3d_cl: unknown epilogue %d", epi);
+            return YUME_EINVAL;
+    }
+}

@@ -1,0 +1,282 @@
+// gemm_core.hpp — the bf16 MFMA GEMM pipeline shared by the dense GEMM (gemm_bf16.hip) and the implicit-GEMM
+// causal convolutions of the VAE (conv3d.hip):   acc[m,n] = sum_k A[m,k] * W[n,k].
+//
+// Tile 128(M) x 128(N) x 64(K), 256 threads = 4 waves in a 2x2 grid, each wave 64x64 = 4x4
+// v_mfma_f32_16x16x32_bf16 accumulators. Both operands are K-contiguous in 16-byte chunks:
+//   HBM -> LDS by LDS-DMA (global_load_lds_dwordx4, 16 B/lane), double buffered, one barrier per K tile.
+//   The LDS image is lane-linear; the bank-conflict swizzle is applied on the SOURCE address
+//   (16-byte chunk c of row r is fetched from logical chunk c ^ (r & 7)) and undone on the ds_read_b128.
+// The A operand is produced by an `ALoad` policy: a row-major matrix (PlainA) or a gather from a
+// channels-last [T,H,W,C] activation with zero padding / causal frame cache / folded 2x upsample (conv3d.hip).
+// Epilogue: accumulators are restaged through LDS per wave so every global access is a full 8/16-byte
+// vector along the contiguous dimension; bias / GELU / gate*y+residual / +addend / transposed (K-major V^T)
+// / frame-interleaved stores are fused there.
+// Workgroup order: bijective XCD remap (block b runs on XCD b%8) + grouped (8 M-tiles) traversal so the
+// blocks resident on one XCD share A row-panels and W column-panels in that XCD's L2.
+#pragma once
+#include "common.hpp"
+
+namespace gemm_core {
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int NTHR = 256;
+constexpr int TILE_BYTES = BM * BK * 2;          // 16 KiB per operand tile
+constexpr int STAGE_BYTES = 2 * TILE_BYTES;      // A + B
+constexpr int LDS_BYTES = 2 * STAGE_BYTES;       // double buffered = 64 KiB
+
+// internal epilogue ids beyond the public YUME_EPI_* (conv3d.hip)
+constexpr int EPI_BF16_ADD = 16;      // out bf16 = acc + bias + add[m, n]   (add bf16, ld = ldadd)
+constexpr int EPI_BF16_TSPLIT = 17;   // out bf16 row m=(t,hw), col n=(j,c) -> out[((2t+j)*HW + hw), c]   (time_conv interleave)
+
+struct Epilogue {
+    const float* bias;
+    void* out; int64_t ldo;
+    const float* gate; int64_t gate_stride; const int32_t* row_idx;
+    unsigned short* outT; int64_t ldt; int n_split;
+    const unsigned short* add; int64_t ldadd;
+    int hw;   // TSPLIT: positions per frame
+};
+
+struct Problem {
+    const unsigned short* W; int64_t ldw;
+    int M, N, K;
+    int tiles_m, tiles_n;
+};
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef __attribute__((address_space(1))) const void gbl_cvoid;
+
+// ---- A loaders -------------------------------------------------------------------------------------------
+// contract: init(m0, tid) once; then for kt = 0,1,2,... in order: src(rr, kt) for rr = 0..3 returns the global
+// address of the 16-byte chunk that belongs at LDS position (row = rr*32 + tid/8, chunk = tid%8), i.e. logical
+// k-chunk (tid%8) ^ (row & 7) of K tile kt; advance() after each tile.
+struct PlainA {
+    const unsigned short* A; int64_t lda; int M;
+    const unsigned short* rowp[4];
+    __device__ __forceinline__ void init(int m0, int tid) {
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const int r = rr * 32 + (tid >> 3);
+            int gr = m0 + r;
+            gr = gr < M ? gr : M - 1;
+            rowp[rr] = A + (int64_t)gr * lda + (((tid & 7) ^ (r & 7)) << 3);
+        }
+    }
+    __device__ __forceinline__ const unsigned short* src(int rr, int kt) const { return rowp[rr] + kt * BK; }
+    __device__ __forceinline__ void advance() {}
+};
+
+__device__ __forceinline__ void stage_b(const unsigned short* __restrict__ W, int64_t ldw, int n0, int N, int k0,
+                                        char* lds_tile, int tid, int wave) {
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+        const int r = rr * 32 + (tid >> 3);
+        const int gc = (tid & 7) ^ (r & 7);
+        int gr = n0 + r;
+        gr = gr < N ? gr : N - 1;
+        const unsigned short* g = W + (int64_t)gr * ldw + k0 + gc * 8;
+        char* l = lds_tile + rr * 4096 + wave * 1024;  // wave-uniform base; hardware adds lane*16
+        __builtin_amdgcn_global_load_lds((gbl_cvoid*)g, (lds_void*)l, 16, 0, 0);
+    }
+}
+
+template <class ALoad>
+__device__ __forceinline__ void stage_a(ALoad& al, int kt, char* lds_tile, int wave) {
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+        const unsigned short* g = al.src(rr, kt);
+        char* l = lds_tile + rr * 4096 + wave * 1024;
+        __builtin_amdgcn_global_load_lds((gbl_cvoid*)g, (lds_void*)l, 16, 0, 0);
+    }
+    al.advance();
+}
+
+__device__ __forceinline__ bf16x8_t lds_frag(const char* tile, int row, int chunk) {
+    const char* p = tile + row * 128 + ((chunk ^ (row & 7)) << 4);
+    return *reinterpret_cast<const bf16x8_t*>(p);
+}
+
+template <int EPI, class ALoad>
+__global__ __launch_bounds__(NTHR, 2) void gemm128_kernel(Problem p, ALoad al, Epilogue e) {
+    __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+
+    // ---- workgroup -> tile (XCD-aware, grouped) ----
+    const int nwg = p.tiles_m * p.tiles_n;
+    int wg;
+    {
+        const int bid = blockIdx.x;
+        const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+        wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    constexpr int GROUP_M = 8;
+    const int width = GROUP_M * p.tiles_n;
+    const int group = wg / width;
+    const int first_m = group * GROUP_M;
+    const int gsz = min(p.tiles_m - first_m, GROUP_M);
+    const int tm = first_m + (wg % width) % gsz;
+    const int tn = (wg % width) / gsz;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = p.K / BK;
+    al.init(m0, tid);
+    stage_a(al, 0, smem, wave);
+    stage_b(p.W, p.ldw, n0, p.N, 0, smem + TILE_BYTES, tid, wave);
+
+    int cur = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        // tile kt has landed (own loads) ...
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // ... for every wave, and every wave is done reading the other buffer
+        __syncthreads();
+        if (kt + 1 < nk) {
+            char* nb = smem + (cur ^ 1) * STAGE_BYTES;
+            stage_a(al, kt + 1, nb, wave);
+            stage_b(p.W, p.ldw, n0, p.N, (kt + 1) * BK, nb + TILE_BYTES, tid, wave);
+        }
+        const char* At = smem + cur * STAGE_BYTES;
+        const char* Bt = At + TILE_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8_t a[4], b[4];
+            const int ch = ks * 4 + (lane >> 4);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[i] = lds_frag(At, wm * 64 + i * 16 + (lane & 15), ch);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b[j] = lds_frag(Bt, wn * 64 + j * 16 + (lane & 15), ch);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        cur ^= 1;
+    }
+    __syncthreads();  // all waves finished with the operand tiles; LDS is reused for the epilogue
+
+    // ---- epilogue: per-wave 64x64 fp32 restage (16 KiB per wave) ----
+    float* ep = reinterpret_cast<float*>(smem) + wave * (64 * 64);
+    const int wm0 = m0 + wm * 64, wn0 = n0 + wn * 64;
+    const bool transposed = (EPI == YUME_EPI_BF16_SPLITT) && (n0 >= e.n_split);
+    if (!transposed) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    ep[(i * 16 + 4 * (lane >> 4) + r) * 64 + j * 16 + (lane & 15)] = acc[i][j][r];
+    } else {
+        // [n][m] image, 4-float granule g of row n stored at granule g ^ (n & 15)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int n = j * 16 + (lane & 15);
+                const int g = i * 4 + (lane >> 4);
+                *reinterpret_cast<f32x4*>(ep + n * 64 + ((g ^ (n & 15)) << 2)) = acc[i][j];
+            }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // own LDS writes done (region is private to the wave)
+    __builtin_amdgcn_wave_barrier();
+
+    const int sub = lane >> 4;         // row within a pass of 4
+    const int c4 = (lane & 15) << 2;   // first of 4 contiguous columns
+    if (!transposed) {
+        const int n = wn0 + c4;
+        f32x4 bias4 = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (e.bias && n < p.N) bias4 = *reinterpret_cast<const f32x4*>(e.bias + n);
+#pragma unroll 4
+        for (int ps = 0; ps < 16; ++ps) {
+            const int rl = ps * 4 + sub;
+            const int m = wm0 + rl;
+            if (m >= p.M || n >= p.N) continue;
+            f32x4 v = *reinterpret_cast<const f32x4*>(ep + rl * 64 + c4);
+            v += bias4;
+            if (EPI == YUME_EPI_BF16 || EPI == YUME_EPI_BF16_GELU || EPI == YUME_EPI_BF16_SPLITT ||
+                EPI == YUME_EPI_BF16_GELU_ERF || EPI == EPI_BF16_ADD || EPI == EPI_BF16_TSPLIT) {
+                if (EPI == YUME_EPI_BF16_GELU) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) v[q] = gelu_tanh(v[q]);
+                }
+                if (EPI == YUME_EPI_BF16_GELU_ERF) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) v[q] = 0.5f * v[q] * (1.0f + erff(v[q] * 0.7071067811865476f));
+                }
+                if (EPI == EPI_BF16_ADD) {
+                    const u32x2 a2 = *reinterpret_cast<const u32x2*>(e.add + (int64_t)m * e.ldadd + n);
+                    v[0] += bf16_to_f32((unsigned short)(a2[0] & 0xffffu));
+                    v[1] += bf16_to_f32((unsigned short)(a2[0] >> 16));
+                    v[2] += bf16_to_f32((unsigned short)(a2[1] & 0xffffu));
+                    v[3] += bf16_to_f32((unsigned short)(a2[1] >> 16));
+                }
+                u32x2 o;
+                o[0] = pack_bf16x2(v[0], v[1]);
+                o[1] = pack_bf16x2(v[2], v[3]);
+                int64_t orow = m;
+                int ocol = n;
+                if (EPI == EPI_BF16_TSPLIT) {
+                    const int ch = p.N >> 1;
+                    const int j = n >= ch ? 1 : 0;
+                    const int t = m / e.hw;
+                    orow = (int64_t)m + (int64_t)(t + j) * e.hw;   // ((2t + j) * hw + (m - t*hw))
+                    ocol = n - j * ch;
+                }
+                *reinterpret_cast<u32x2*>(reinterpret_cast<unsigned short*>(e.out) + orow * e.ldo + ocol) = o;
+            } else if (EPI == YUME_EPI_F32) {
+                *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(e.out) + (int64_t)m * e.ldo + n) = v;
+            } else {  // YUME_EPI_RESID
+                float* xo = reinterpret_cast<float*>(e.out) + (int64_t)m * e.ldo + n;
+                f32x4 x = *reinterpret_cast<const f32x4*>(xo);
+                if (e.gate) {
+                    const int64_t row = e.row_idx ? (int64_t)e.row_idx[m] : 0;
+                    const f32x4 g = *reinterpret_cast<const f32x4*>(e.gate + row * e.gate_stride + n);
+                    x += v * g;
+                } else {
+                    x += v;
+                }
+                *reinterpret_cast<f32x4*>(xo) = x;
+            }
+        }
+    } else {
+        // rows of the image are output features n, columns are tokens m
+        const int m = wm0 + c4;
+#pragma unroll 4
+        for (int ps = 0; ps < 16; ++ps) {
+            const int nl = ps * 4 + sub;
+            const int n = wn0 + nl;
+            if (n >= p.N || m >= p.M) continue;
+            const int g = lane & 15;
+            f32x4 v = *reinterpret_cast<const f32x4*>(ep + nl * 64 + ((g ^ (nl & 15)) << 2));
+            const float bn = e.bias ? e.bias[n] : 0.f;
+            unsigned short* dst = e.outT + (int64_t)(n - e.n_split) * e.ldt + m;
+            if (m + 3 < p.M) {
+                u32x2 o;
+                o[0] = pack_bf16x2(v[0] + bn, v[1] + bn);
+                o[1] = pack_bf16x2(v[2] + bn, v[3] + bn);
+                *reinterpret_cast<u32x2*>(dst) = o;
+            } else {
+                for (int q = 0; q < 4 && m + q < p.M; ++q) dst[q] = f32_to_bf16(v[q] + bn);
+            }
+        }
+    }
+}
+
+template <int EPI, class ALoad>
+int launch(const Problem& p, const ALoad& al, const Epilogue& e, hipStream_t st, const char* what) {
+    dim3 grid((unsigned)(p.tiles_m * p.tiles_n)), block(NTHR);
+    hipLaunchKernelGGL((gemm128_kernel<EPI, ALoad>), grid, block, 0, st, p, al, e);
+    YUME_CHECK_LAUNCH(what);
+    return YUME_OK;
+}
+
+}  // namespace gemm_core

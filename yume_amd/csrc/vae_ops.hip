@@ -1,0 +1,300 @@
+// vae_ops.hip — the HBM-bound pieces of the causal 3D VAE on channels-last bf16 activations:
+// RMS_norm(+SiLU), DupUp3D / AvgDown3D shortcut adds, row softmax of the single-head attention, and the
+// NCTHW fp32 <-> channels-last bf16 layout conversions (with patchify / unpatchify / latent scaling / clamp).
+// Roofline: HBM. Algorithmic bytes per element: rmsnorm_silu 2 read + 2 write.
+#include "common.hpp"
+
+namespace {
+
+// ---- RMS_norm (+SiLU): LPR lanes cooperate on one row, 64/LPR rows per wave, 4 waves per workgroup ----
+template <int LPR, int NV>
+__global__ __launch_bounds__(256) void rmsnorm_silu_kernel(const unsigned short* __restrict__ x, int64_t ldx, int64_t M,
+                                                           int C, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, int silu_on,
+                                                           unsigned short* __restrict__ y, int64_t ldy) {
+    constexpr int RPW = 64 / LPR;
+    const int lane = threadIdx.x & 63;
+    const int sub = lane % LPR;
+    const int64_t row = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW + lane / LPR;
+    const bool live = row < M;
+    const int nvec = C >> 3;
+    u16x8 v[NV];
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int vi = sub + i * LPR;
+        if (live && vi < nvec) {
+            v[i] = *reinterpret_cast<const u16x8*>(x + row * ldx + 8 * vi);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float f = bf16_to_f32(v[i][j]);
+                ss += f * f;
+            }
+        }
+    }
+#pragma unroll
+    for (int o = LPR / 2; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+    const float inv = sqrtf((float)C) / fmaxf(sqrtf(ss), 1e-12f);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int vi = sub + i * LPR;
+        if (live && vi < nvec) {
+            const f32x4 g0 = *reinterpret_cast<const f32x4*>(gamma + 8 * vi);
+            const f32x4 g1 = *reinterpret_cast<const f32x4*>(gamma + 8 * vi + 4);
+            f32x4 b0 = f32x4{0.f, 0.f, 0.f, 0.f}, b1 = b0;
+            if (beta) {
+                b0 = *reinterpret_cast<const f32x4*>(beta + 8 * vi);
+                b1 = *reinterpret_cast<const f32x4*>(beta + 8 * vi + 4);
+            }
+            float o[8];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                o[j] = bf16_to_f32(v[i][j]) * inv * g0[j] + b0[j];
+                o[4 + j] = bf16_to_f32(v[i][4 + j]) * inv * g1[j] + b1[j];
+            }
+            if (silu_on) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] = silu(o[j]);
+            }
+            u32x4 w;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) w[j] = pack_bf16x2(o[2 * j], o[2 * j + 1]);
+            *reinterpret_cast<u32x4*>(y + row * ldy + 8 * vi) = w;
+        }
+    }
+}
+
+// ---- DupUp3D add: one thread per (output position, 8 output channels) ----
+__global__ __launch_bounds__(256) void dupup_add_kernel(const unsigned short* __restrict__ x, int64_t ldx, int Tin, int Hin,
+                                                        int Win, int Cin, unsigned short* __restrict__ y, int64_t ldy,
+                                                        int To, int Cout, int ft, int fs, int toff) {
+    const int Ho = Hin * fs, Wo = Win * fs;
+    const int cv = Cout >> 3;
+    const int64_t total = (int64_t)To * Ho * Wo * cv;
+    const int F = ft * fs * fs;
+    const int repeats = Cout * F / Cin;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c8 = (int)(i % cv);
+        const int64_t pos = i / cv;
+        const int wo = (int)(pos % Wo);
+        const int ho = (int)((pos / Wo) % Ho);
+        const int to = (int)(pos / ((int64_t)Wo * Ho));
+        const int tt = to + toff;
+        const int ti = tt / ft, a = tt % ft;
+        const int hi = ho / fs, b = ho % fs, wi = wo / fs, c = wo % fs;
+        const int phase = (a * fs + b) * fs + c;
+        const unsigned short* xr = x + (((int64_t)ti * Hin + hi) * Win + wi) * ldx;
+        unsigned short* yr = y + pos * ldy + 8 * c8;
+        u32x4 yv = *reinterpret_cast<const u32x4*>(yr);
+        float o[8];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            o[2 * j] = bf16_to_f32((unsigned short)(yv[j] & 0xffffu));
+            o[2 * j + 1] = bf16_to_f32((unsigned short)(yv[j] >> 16));
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int oc = 8 * c8 + j;
+            o[j] += bf16_to_f32(xr[(oc * F + phase) / repeats]);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) yv[j] = pack_bf16x2(o[2 * j], o[2 * j + 1]);
+        *reinterpret_cast<u32x4*>(yr) = yv;
+    }
+}
+
+// ---- AvgDown3D add: one thread per (output position, output channel) ----
+__global__ __launch_bounds__(256) void avgdown_add_kernel(const unsigned short* __restrict__ x, int64_t ldx, int Tin, int Hin,
+                                                          int Win, int Cin, unsigned short* __restrict__ y, int64_t ldy,
+                                                          int Cout, int ft, int fs) {
+    const int padt = (ft - Tin % ft) % ft;
+    const int To = (Tin + padt) / ft, Ho = Hin / fs, Wo = Win / fs;
+    const int F = ft * fs * fs;
+    const int G = Cin * F / Cout;
+    const int64_t total = (int64_t)To * Ho * Wo * Cout;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int oc = (int)(i % Cout);
+        const int64_t pos = i / Cout;
+        const int wo = (int)(pos % Wo);
+        const int ho = (int)((pos / Wo) % Ho);
+        const int to = (int)(pos / ((int64_t)Wo * Ho));
+        float s = 0.f;
+        for (int g = 0; g < G; ++g) {
+            const int idx = oc * G + g;            // index into the (ci, a, b, c) unfolded channel axis
+            const int ci = idx / F, ph = idx % F;
+            const int c = ph % fs, b = (ph / fs) % fs, a = ph / (fs * fs);
+            const int ti = to * ft + a - padt;
+            if (ti >= 0) s += bf16_to_f32(x[(((int64_t)ti * Hin + ho * fs + b) * Win + wo * fs + c) * ldx + ci]);
+        }
+        unsigned short* yp = y + pos * ldy + oc;
+        *yp = f32_to_bf16(bf16_to_f32(*yp) + s / (float)G);
+    }
+}
+
+// ---- row softmax: one workgroup per row, three passes over a (cache resident) fp32 row ----
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ S, int64_t lds_, int n, float scale,
+                                                           unsigned short* __restrict__ P, int64_t ldp) {
+    __shared__ float red[8];
+    const float* s = S + (int64_t)blockIdx.x * lds_;
+    unsigned short* p = P + (int64_t)blockIdx.x * ldp;
+    float mx = -3.0e38f;
+    for (int i = threadIdx.x; i < n; i += 256) mx = fmaxf(mx, s[i]);
+    mx = wave_max(mx);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+    const float c = scale * 1.4426950408889634f;
+    float sum = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) sum += __builtin_amdgcn_exp2f((s[i] - mx) * c);
+    sum = wave_sum(sum);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = sum;
+    __syncthreads();
+    const float inv = 1.0f / (red[0] + red[1] + red[2] + red[3]);
+    for (int i = threadIdx.x; i < (int)ldp; i += 256)
+        p[i] = i < n ? f32_to_bf16(__builtin_amdgcn_exp2f((s[i] - mx) * c) * inv) : (unsigned short)0;
+}
+
+// ---- NCTHW -> channels-last (+ patchify, per-channel affine) ----
+template <bool INBF16>
+__global__ __launch_bounds__(256) void pack_input_kernel(const void* __restrict__ xv, int C, int T, int H, int W, int ps,
+                                                         const float* __restrict__ mul, const float* __restrict__ add,
+                                                         unsigned short* __restrict__ out, int Cpad) {
+    const int Ho = H / ps, Wo = W / ps;
+    const int64_t total = (int64_t)T * Ho * Wo * Cpad;
+    const int Cv = C * ps * ps;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int oc = (int)(i % Cpad);
+        const int64_t pos = i / Cpad;
+        unsigned short val = 0;
+        if (oc < Cv) {
+            const int wo = (int)(pos % Wo);
+            const int ho = (int)((pos / Wo) % Ho);
+            const int t = (int)(pos / ((int64_t)Wo * Ho));
+            // oc = c*ps*ps + r*ps + q  ->  x[c, t, ho*ps + q, wo*ps + r]
+            const int q = oc % ps, r = (oc / ps) % ps, c = oc / (ps * ps);
+            const int64_t idx = (((int64_t)c * T + t) * H + ho * ps + q) * W + wo * ps + r;
+            float f = INBF16 ? bf16_to_f32(reinterpret_cast<const unsigned short*>(xv)[idx])
+                             : reinterpret_cast<const float*>(xv)[idx];
+            if (mul) f = f * mul[c] + add[c];
+            val = f32_to_bf16(f);
+        }
+        out[i] = val;
+    }
+}
+
+// ---- channels-last -> NCTHW fp32 (+ unpatchify, (x - sub) * mul, clamp) ----
+__global__ __launch_bounds__(256) void unpack_output_kernel(const unsigned short* __restrict__ x, int64_t ldx, int T, int H,
+                                                            int W, int Cv, int ps, const float* __restrict__ sub,
+                                                            const float* __restrict__ mul, float lo, float hi,
+                                                            float* __restrict__ out) {
+    const int Co = Cv / (ps * ps), Ho = H * ps, Wo = W * ps;
+    const int64_t total = (int64_t)Co * T * Ho * Wo;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int w = (int)(i % Wo);
+        const int h = (int)((i / Wo) % Ho);
+        const int t = (int)((i / ((int64_t)Wo * Ho)) % T);
+        const int c = (int)(i / ((int64_t)Wo * Ho * T));
+        const int q = h % ps, r = w % ps;
+        const int ic = c * ps * ps + r * ps + q;
+        float f = bf16_to_f32(x[(((int64_t)t * H + h / ps) * W + w / ps) * ldx + ic]);
+        if (mul) f = (f - sub[c]) * mul[c];
+        if (lo < hi) f = fminf(fmaxf(f, lo), hi);
+        out[i] = f;
+    }
+}
+
+inline unsigned grid_for(int64_t total, int per_block = 256, int64_t cap = 16384) {
+    int64_t nb = (total + per_block - 1) / per_block;
+    if (nb > cap) nb = cap;
+    if (nb < 1) nb = 1;
+    return (unsigned)nb;
+}
+
+}  // namespace
+
+extern "C" int yume_vae_rmsnorm_silu(const void* x, int64_t ldx, int64_t M, int64_t C, const float* gamma, const float* beta,
+                                     int silu_on, void* y, int64_t ldy, void* stream) {
+    YUME_REQUIRE(x && gamma && y, "vae_rmsnorm_silu: NULL pointer");
+    YUME_REQUIRE(M > 0 && C > 0 && (C % 8) == 0 && C <= 4096 && (ldx % 8) == 0 && (ldy % 8) == 0, "vae_rmsnorm_silu: C=%lld must be a multiple of 8 and <= 4096", (long long)C);
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned short* xp = (const unsigned short*)x;
+    unsigned short* yp = (unsigned short*)y;
+    const int nvec = (int)(C / 8);
+#define LAUNCH_RMS(LPR, NV)                                                                                          \
+    hipLaunchKernelGGL((rmsnorm_silu_kernel<LPR, NV>), dim3((unsigned)((M + 4 * (64 / LPR) - 1) / (4 * (64 / LPR)))), \
+                       dim3(256), 0, st, xp, ldx, M, (int)C, gamma, beta, silu_on, yp, ldy)
+    if (nvec <= 8) LAUNCH_RMS(8, 1);
+    else if (nvec <= 16) LAUNCH_RMS(16, 1);
+    else if (nvec <= 32) LAUNCH_RMS(32, 1);
+    else if (nvec <= 64) LAUNCH_RMS(64, 1);
+    else if (nvec <= 128) LAUNCH_RMS(64, 2);
+    else if (nvec <= 256) LAUNCH_RMS(64, 4);
+    else LAUNCH_RMS(64, 8);
+#undef LAUNCH_RMS
+    YUME_CHECK_LAUNCH("vae_rmsnorm_silu");
+    return YUME_OK;
+}
+
+extern "C" int yume_vae_dupup_add(const void* x, int64_t ldx, int64_t Tin, int64_t Hin, int64_t Win, int64_t Cin, void* y,
+                                  int64_t ldy, int64_t To, int64_t Cout, int ft, int fs, int toff, void* stream) {
+    YUME_REQUIRE(x && y, "vae_dupup_add: NULL pointer");
+    YUME_REQUIRE(ft >= 1 && fs >= 1 && (Cout % 8) == 0 && (ldy % 8) == 0, "vae_dupup_add: bad shape");
+    YUME_REQUIRE((Cout * ft * fs * fs) % Cin == 0, "vae_dupup_add: Cout*factor must be a multiple of Cin");
+    YUME_REQUIRE(toff >= 0 && To + toff <= Tin * ft, "vae_dupup_add: frame range");
+    const int64_t total = To * Hin * fs * Win * fs * (Cout / 8);
+    hipLaunchKernelGGL(dupup_add_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const unsigned short*)x,
+                       ldx, (int)Tin, (int)Hin, (int)Win, (int)Cin, (unsigned short*)y, ldy, (int)To, (int)Cout, ft, fs, toff);
+    YUME_CHECK_LAUNCH("vae_dupup_add");
+    return YUME_OK;
+}
+
+extern "C" int yume_vae_avgdown_add(const void* x, int64_t ldx, int64_t Tin, int64_t Hin, int64_t Win, int64_t Cin, void* y,
+                                    int64_t ldy, int64_t Cout, int ft, int fs, void* stream) {
+    YUME_REQUIRE(x && y, "vae_avgdown_add: NULL pointer");
+    YUME_REQUIRE(ft >= 1 && fs >= 1 && (Hin % fs) == 0 && (Win % fs) == 0, "vae_avgdown_add: H, W must be multiples of factor_s");
+    YUME_REQUIRE((Cin * ft * fs * fs) % Cout == 0, "vae_avgdown_add: Cin*factor must be a multiple of Cout");
+    const int64_t padt = (ft - Tin % ft) % ft;
+    const int64_t total = ((Tin + padt) / ft) * (Hin / fs) * (Win / fs) * Cout;
+    hipLaunchKernelGGL(avgdown_add_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const unsigned short*)x,
+                       ldx, (int)Tin, (int)Hin, (int)Win, (int)Cin, (unsigned short*)y, ldy, (int)Cout, ft, fs);
+    YUME_CHECK_LAUNCH("vae_avgdown_add");
+    return YUME_OK;
+}
+
+extern "C" int yume_softmax_rows(const float* S, int64_t lds_, int64_t R, int64_t n, float scale, void* P, int64_t ldp,
+                                 void* stream) {
+    YUME_REQUIRE(S && P, "softmax_rows: NULL pointer");
+    YUME_REQUIRE(R > 0 && n > 0 && ldp >= n && lds_ >= n && n < (1ll << 30), "softmax_rows: bad shape");
+    hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)R), dim3(256), 0, (hipStream_t)stream, S, lds_, (int)n, scale,
+                       (unsigned short*)P, ldp);
+    YUME_CHECK_LAUNCH("softmax_rows");
+    return YUME_OK;
+}
+
+extern "C" int yume_vae_pack_input(const void* x, int in_bf16, int64_t C, int64_t T, int64_t H, int64_t W, int ps,
+                                   const float* mul, const float* add, void* out, int64_t Cpad, void* stream) {
+    YUME_REQUIRE(x && out, "vae_pack_input: NULL pointer");
+    YUME_REQUIRE(ps >= 1 && (H % ps) == 0 && (W % ps) == 0 && Cpad >= C * ps * ps, "vae_pack_input: bad shape");
+    YUME_REQUIRE((mul == nullptr) == (add == nullptr), "vae_pack_input: mul and add go together");
+    const int64_t total = T * (H / ps) * (W / ps) * Cpad;
+    hipStream_t st = (hipStream_t)stream;
+    if (in_bf16)
+        hipLaunchKernelGGL(pack_input_kernel<true>, dim3(grid_for(total)), dim3(256), 0, st, x, (int)C, (int)T, (int)H, (int)W, ps, mul, add, (unsigned short*)out, (int)Cpad);
+    else
+        hipLaunchKernelGGL(pack_input_kernel<false>, dim3(grid_for(total)), dim3(256), 0, st, x, (int)C, (int)T, (int)H, (int)W, ps, mul, add, (unsigned short*)out, (int)Cpad);
+    YUME_CHECK_LAUNCH("vae_pack_input");
+    return YUME_OK;
+}
+
+extern "C" int yume_vae_unpack_output(const void* x, int64_t ldx, int64_t T, int64_t H, int64_t W, int64_t Cv, int ps,
+                                      const float* sub, const float* mul, float lo, float hi, float* out, void* stream) {
+    YUME_REQUIRE(x && out, "vae_unpack_output: NULL pointer");
+    YUME_REQUIRE(ps >= 1 && (Cv % (ps * ps)) == 0 && ldx >= Cv, "vae_unpack_output: bad shape");
+    YUME_REQUIRE((mul == nullptr) == (sub == nullptr), "vae_unpack_output: sub and mul go together");
+    const int64_t total = (Cv / (ps * ps)) * T * H * ps * W * ps;
+    hipLaunchKernelGGL(unpack_output_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const unsigned short*)x,
+                       ldx, (int)T, (int)H, (int)W, (int)Cv, ps, sub, mul, lo, hi, out);
+    YUME_CHECK_LAUNCH("vae_unpack_output");
+    return YUME_OK;
+}

@@ -171,3 +171,115 @@ def randomize_module_(model, seed=0):
             v = (torch.rand(shape, generator=g, device=dev) * 2 - 1) * a
         p.copy_(v.to(p.dtype))
     return model
+
+
+# ----------------------------------------------------------------------------------------------- VAE
+# WanVAE_ configurations: wan23/modules/vae2_2.py:748-790,909-1043 (Wan2.2) and wan/modules/vae.py:483-509,591-617 (Wan2.1)
+VAE_CFG_22 = dict(version="2.2", dim=160, dec_dim=256, z_dim=48, dim_mult=[1, 2, 4, 4], num_res_blocks=2,
+                  temperal_downsample=[False, True, True], patch=2, in_ch=12)
+VAE_CFG_21 = dict(version="2.1", dim=96, dec_dim=96, z_dim=16, dim_mult=[1, 2, 4, 4], num_res_blocks=2,
+                  temperal_downsample=[False, True, True], patch=1, in_ch=3)
+
+
+def tiny_vae_cfg(version, dim=32, dec_dim=None):
+    base = dict(VAE_CFG_22 if version == "2.2" else VAE_CFG_21)
+    base["dim"] = dim
+    base["dec_dim"] = dec_dim if dec_dim is not None else (dim if version == "2.1" else 2 * dim)
+    return base
+
+
+def vae_param_shapes(cfg):
+    """state_dict key -> shape of the reference WanVAE_ (both versions), in module order."""
+    v22 = cfg["version"] == "2.2"
+    z, nres, mult = cfg["z_dim"], cfg["num_res_blocks"], cfg["dim_mult"]
+    tds = cfg["temperal_downsample"]
+    sh = {}
+
+    def conv(name, cin, cout, k):
+        sh[name + ".weight"] = (cout, cin) + tuple(k)
+        sh[name + ".bias"] = (cout,)
+
+    def res(name, cin, cout):
+        sh[name + ".residual.0.gamma"] = (cin, 1, 1, 1)
+        conv(name + ".residual.2", cin, cout, (3, 3, 3))
+        sh[name + ".residual.3.gamma"] = (cout, 1, 1, 1)
+        conv(name + ".residual.6", cout, cout, (3, 3, 3))
+        if cin != cout:
+            conv(name + ".shortcut", cin, cout, (1, 1, 1))
+
+    def attn(name, c):
+        sh[name + ".norm.gamma"] = (c, 1, 1)
+        conv(name + ".to_qkv", c, 3 * c, (1, 1))
+        conv(name + ".proj", c, c, (1, 1))
+
+    def resamp(name, c, mode):
+        if mode.startswith("up"):
+            conv(name + ".resample.1", c, c if v22 else c // 2, (3, 3))
+            if mode == "upsample3d":
+                conv(name + ".time_conv", c, 2 * c, (3, 1, 1))
+        else:
+            conv(name + ".resample.1", c, c, (3, 3))
+            if mode == "downsample3d":
+                conv(name + ".time_conv", c, c, (3, 1, 1))
+
+    # encoder
+    dims = [cfg["dim"] * u for u in [1] + mult]
+    conv("encoder.conv1", cfg["in_ch"], dims[0], (3, 3, 3))
+    li = 0
+    for i, (cin, cout) in enumerate(zip(dims[:-1], dims[1:])):
+        down = i != len(mult) - 1
+        mode = "downsample3d" if (tds[i] if i < len(tds) else False) else "downsample2d"
+        for j in range(nres):
+            res(f"encoder.downsamples.{i}.downsamples.{j}" if v22 else f"encoder.downsamples.{li}", cin, cout)
+            cin = cout
+            li += 1
+        if down:
+            resamp(f"encoder.downsamples.{i}.downsamples.{nres}" if v22 else f"encoder.downsamples.{li}", cout, mode)
+            li += 1
+    res("encoder.middle.0", cout, cout)
+    attn("encoder.middle.1", cout)
+    res("encoder.middle.2", cout, cout)
+    sh["encoder.head.0.gamma"] = (cout, 1, 1, 1)
+    conv("encoder.head.2", cout, 2 * z, (3, 3, 3))
+    conv("conv1", 2 * z, 2 * z, (1, 1, 1))
+    conv("conv2", z, z, (1, 1, 1))
+    # decoder
+    dims = [cfg["dec_dim"] * u for u in [mult[-1]] + mult[::-1]]
+    tus = tds[::-1]
+    conv("decoder.conv1", z, dims[0], (3, 3, 3))
+    res("decoder.middle.0", dims[0], dims[0])
+    attn("decoder.middle.1", dims[0])
+    res("decoder.middle.2", dims[0], dims[0])
+    li = 0
+    for i, (cin, cout) in enumerate(zip(dims[:-1], dims[1:])):
+        up = i != len(mult) - 1
+        mode = "upsample3d" if (tus[i] if i < len(tus) else False) else "upsample2d"
+        if not v22 and i in (1, 2, 3):
+            cin = cin // 2
+        for j in range(nres + 1):
+            res(f"decoder.upsamples.{i}.upsamples.{j}" if v22 else f"decoder.upsamples.{li}", cin, cout)
+            cin = cout
+            li += 1
+        if up:
+            resamp(f"decoder.upsamples.{i}.upsamples.{nres + 1}" if v22 else f"decoder.upsamples.{li}", cout, mode)
+            li += 1
+    sh["decoder.head.0.gamma"] = (cout, 1, 1, 1)
+    conv("decoder.head.2", cout, cfg["in_ch"], (3, 3, 3))
+    return sh
+
+
+def make_vae_state_dict(cfg, seed=0, device="cpu"):
+    sd = {}
+    for k, shape in vae_param_shapes(cfg).items():
+        g = _gen(seed, k)
+        if k.endswith("gamma"):
+            v = 1.0 + _normal(shape, 0.1, g)
+        elif k.endswith("bias"):
+            v = _normal(shape, 0.02, g)
+        else:
+            fan_in = 1
+            for s in shape[1:]:
+                fan_in *= s
+            v = _uniform(shape, math.sqrt(3.0 / fan_in), g)
+        sd[k] = v.to(device)
+    return sd
