@@ -66,40 +66,43 @@ def gemm_ref(a, w, bias):
 
 
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 256, 192), (1, 128, 64), (129, 384, 3072), (1000, 192, 1536),
-                                   (257, 512, 1280), (2048, 1024, 512)])
-def test_gemm_bf16_plain_and_f32(M, N, K):
+                                   (257, 512, 1280), (2048, 1024, 512), (700, 520, 4096)])
+@pytest.mark.parametrize("variant", [1, 2])
+def test_gemm_bf16_plain_and_f32(M, N, K, variant):
     a, w, bias = rnd(M, K, seed=1, dtype=torch.bfloat16), rnd(N, K, seed=2, scale=K ** -0.5, dtype=torch.bfloat16), rnd(N, seed=3)
     want = gemm_ref(a, w, bias)
     ad, wd, bd = a.to(DEV), w.to(DEV), bias.to(DEV)
     o32 = torch.empty(M, N, dtype=torch.float32, device=DEV)
-    ops.gemm_bf16(ad, wd, bd, o32, ops.EPI_F32)
+    ops.gemm_bf16(ad, wd, bd, o32, ops.EPI_F32, variant=variant)
     assert rel_l2(o32.cpu(), want) < 2e-6 * math.sqrt(K) + 1e-6          # fp32 accumulation of exact bf16 products
     assert (o32.cpu().double() - want).abs().max() < 1e-4 * max(1.0, want.abs().max().item())
     o16 = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
-    ops.gemm_bf16(ad, wd, bd, o16, ops.EPI_BF16)
+    ops.gemm_bf16(ad, wd, bd, o16, ops.EPI_BF16, variant=variant)
     assert (o16.cpu().double() - want).abs().max() <= 2.0 ** -8 * want.abs().max() + 1e-6
     og = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
-    ops.gemm_bf16(ad, wd, bd, og, ops.EPI_BF16_GELU)
+    ops.gemm_bf16(ad, wd, bd, og, ops.EPI_BF16_GELU, variant=variant)
     wg = torch.nn.functional.gelu(want, approximate="tanh")
     assert (og.cpu().double() - wg).abs().max() <= 2.0 ** -7 * wg.abs().max() + 1e-5
     oe = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
-    ops.gemm_bf16(ad, wd, bd, oe, ops.EPI_BF16_GELU_ERF)
+    ops.gemm_bf16(ad, wd, bd, oe, ops.EPI_BF16_GELU_ERF, variant=variant)
     we = torch.nn.functional.gelu(want)
     assert (oe.cpu().double() - we).abs().max() <= 2.0 ** -7 * we.abs().max() + 1e-5
 
 
-def test_gemm_detects_transpose_and_permutation():
+@pytest.mark.parametrize("variant", [1, 2])
+def test_gemm_detects_transpose_and_permutation(variant):
     """A = I-like and asymmetric W: a swapped row/col in the C-write or a k-permutation mismatch cannot pass."""
     M, N, K = 256, 256, 256
     a = torch.eye(M, K)
     w = (torch.arange(N).view(N, 1) * 3 + torch.arange(K).view(1, K) % 7).float() / 64
     o = torch.empty(M, N, dtype=torch.float32, device=DEV)
-    ops.gemm_bf16(a.to(torch.bfloat16).to(DEV), w.to(torch.bfloat16).to(DEV), None, o, ops.EPI_F32)
+    ops.gemm_bf16(a.to(torch.bfloat16).to(DEV), w.to(torch.bfloat16).to(DEV), None, o, ops.EPI_F32, variant=variant)
     assert torch.equal(o.cpu(), w.to(torch.bfloat16).float().t().contiguous())
 
 
 @pytest.mark.parametrize("M,N,K,R", [(300, 512, 512, 2), (130, 3072, 1024, 1)])
-def test_gemm_resid_gate(M, N, K, R):
+@pytest.mark.parametrize("variant", [1, 2])
+def test_gemm_resid_gate(M, N, K, R, variant):
     a, w, bias = rnd(M, K, seed=1, dtype=torch.bfloat16), rnd(N, K, seed=2, scale=K ** -0.5, dtype=torch.bfloat16), rnd(N, seed=3)
     x = rnd(M, N, seed=4)
     tab = rnd(R, 6, N, seed=5)
@@ -107,16 +110,17 @@ def test_gemm_resid_gate(M, N, K, R):
     xd = x.to(DEV).clone()
     tabd = tab.to(DEV)
     ops.gemm_bf16(a.to(DEV), w.to(DEV), bias.to(DEV), xd, ops.EPI_RESID, gate=tabd[:, 2], gate_stride=6 * N,
-                  row_idx=idx.to(DEV) if R > 1 else None)
+                  row_idx=idx.to(DEV) if R > 1 else None, variant=variant)
     want = x.double() + gemm_ref(a, w, bias) * tab[idx.long() if R > 1 else torch.zeros(M, dtype=torch.long), 2].double()
     assert (xd.cpu().double() - want).abs().max() < 1e-4 * max(1.0, want.abs().max().item())
     xd2 = x.to(DEV).clone()
-    ops.gemm_bf16(a.to(DEV), w.to(DEV), bias.to(DEV), xd2, ops.EPI_RESID)
+    ops.gemm_bf16(a.to(DEV), w.to(DEV), bias.to(DEV), xd2, ops.EPI_RESID, variant=variant)
     assert (xd2.cpu().double() - (x.double() + gemm_ref(a, w, bias))).abs().max() < 1e-4 * max(1.0, want.abs().max().item())
 
 
 @pytest.mark.parametrize("M", [64, 301, 516])
-def test_gemm_split_transposed(M):
+@pytest.mark.parametrize("variant", [1, 2])
+def test_gemm_split_transposed(M, variant):
     C, K = 256, 512
     N = 3 * C
     a, w, bias = rnd(M, K, seed=1, dtype=torch.bfloat16), rnd(N, K, seed=2, scale=K ** -0.5, dtype=torch.bfloat16), rnd(N, seed=3)
@@ -124,7 +128,7 @@ def test_gemm_split_transposed(M):
     Mp = (M + 7) // 8 * 8
     qk = torch.empty(M, 2 * C, dtype=torch.bfloat16, device=DEV)
     vt = torch.zeros(C, Mp, dtype=torch.bfloat16, device=DEV)
-    ops.gemm_bf16(a.to(DEV), w.to(DEV), bias.to(DEV), qk, ops.EPI_BF16_SPLITT, out_t=vt, n_split=2 * C)
+    ops.gemm_bf16(a.to(DEV), w.to(DEV), bias.to(DEV), qk, ops.EPI_BF16_SPLITT, out_t=vt, n_split=2 * C, variant=variant)
     tol = 2.0 ** -8 * want.abs().max() + 1e-6
     assert (qk.cpu().double() - want[:, :2 * C]).abs().max() <= tol
     assert (vt.cpu()[:, :M].double() - want[:, 2 * C:].t()).abs().max() <= tol

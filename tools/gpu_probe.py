@@ -35,7 +35,7 @@ def main():
     res = {"device": torch.cuda.get_device_name(0)}
     L, C, H, FF = 9460, 3072, 24, 14336
     bf = lambda *s: (torch.randn(*s, device=DEV) * 0.5).to(torch.bfloat16)
-    variants = [int(v) for v in os.environ.get("YUME_GEMM_VARIANTS", "0").split(",")]
+    variants = [int(v) for v in os.environ.get("YUME_GEMM_VARIANTS", "1,2").split(",")]
     # ---- GEMMs
     shapes = {"qkv": (L, 3 * C, C), "o": (L, C, C), "ffn1": (L, FF, C), "ffn2": (L, C, FF), "sq4096": (4096, 4096, 4096),
               "sq8192": (8192, 8192, 8192)}

@@ -30,6 +30,17 @@ constexpr int VROW = 136;                  // bytes per V^T row in LDS (128 + 8 
 constexpr int V_TILE_BYTES = D * VROW;     // 17408
 constexpr int BUF_BYTES = K_TILE_BYTES + V_TILE_BYTES;
 constexpr float NEG_BIG = -1.0e30f;
+constexpr float DEFER_LOG2 = 8.0f;         // deferred-rescale threshold in the log2 domain (P <= 256)
+
+// max / sum across the two 32-lane halves of a wave: one v_permlane32_swap instead of an LDS shuffle
+__device__ __forceinline__ float xhalf_max(float v) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float xhalf_sum(float v) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
 
 struct AttnArgs {
     const unsigned short* Q; int64_t ldq;
@@ -183,24 +194,30 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(AttnArgs p) {
         for (int b = 0; b < 2; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[b][r]);
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        mx = xhalf_max(mx);                                   // combine with the partner lane (other 32 keys)
         const float m_new = fmaxf(m_run, mx * p.scale_log2);
-        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-        m_run = m_new;
+        // deferred rescale: keep the old reference max while it is within 2^DEFER of the new one for every
+        // query of the wave (P <= 2^DEFER then; O/l is invariant to the reference) — the O-wide multiply is
+        // skipped on most tiles. The previous tile's P.V is complete here, so O, l and m move together.
+        if (!__all(m_new - m_run <= DEFER_LOG2)) {
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+            m_run = m_new;
+            l_run *= alpha;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
+        }
         float psum = 0.f;
 #pragma unroll
         for (int b = 0; b < 2; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float pv = __builtin_amdgcn_exp2f(fmaf(sacc[b][r], p.scale_log2, -m_new));
+                const float pv = __builtin_amdgcn_exp2f(fmaf(sacc[b][r], p.scale_log2, -m_run));
                 sacc[b][r] = pv;
                 psum += pv;
             }
-        l_run = l_run * alpha + psum;
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
+        l_run += psum;
 
         // ---- P^T -> bf16 B fragments: k-step s uses block s>>1, regs 8*(s&1) .. +7 ----
         bf16x8_t pf[4];
@@ -238,7 +255,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(AttnArgs p) {
     }
 
     // ---- epilogue: O[q, d] = O^T[d, q] / l ----
-    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float l_tot = xhalf_sum(l_run);
     const float inv = 1.0f / l_tot;
     const int q = q0 + ql;
     if (q < p.Lq) {

@@ -41,15 +41,15 @@ void yume_set_error(const char* fmt, ...);
 __device__ __forceinline__ float bf16_to_f32(unsigned short h) {
     return __uint_as_float(((unsigned int)h) << 16);
 }
-// round-to-nearest-even, NaN preserved (quiet)
-__device__ __forceinline__ unsigned short f32_to_bf16(float f) {
-    unsigned int u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (unsigned short)(u >> 16);
-}
+// round-to-nearest-even in hardware: both lower to v_cvt_pk_bf16_f32 on gfx950
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
 __device__ __forceinline__ unsigned int pack_bf16x2(float lo, float hi) {
-    return (unsigned int)f32_to_bf16(lo) | ((unsigned int)f32_to_bf16(hi) << 16);
+    const f32x2_t v = {lo, hi};
+    return __builtin_bit_cast(unsigned int, __builtin_convertvector(v, bf16x2_t));
+}
+__device__ __forceinline__ unsigned short f32_to_bf16(float f) {
+    return (unsigned short)(pack_bf16x2(f, 0.f) & 0xffffu);
 }
 
 // ---- wave / block reductions --------------------------------------------------------------

@@ -29,10 +29,10 @@ struct ConvA {
     int t0[4], h0[4], w0[4];
     int cin, dt, dh, dw;
 
-    __device__ __forceinline__ void init(int m0, int tid) {
+    __device__ __forceinline__ void init(int m0, int tid, int rpr = 32) {
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
-            int m = m0 + rr * 32 + (tid >> 3);
+            int m = m0 + rr * rpr + (tid >> 3);
             m = m < M ? m : M - 1;
             const int wo = m % Wo;
             const int ho = (m / Wo) % Ho;
@@ -90,6 +90,7 @@ extern "C" int yume_conv3d_cl(const void* x, const void* cache, int64_t ldc, int
                               int kw, int st, int sh, int sw, int pt, int ph, int pw, int ups, int64_t To, int64_t Ho,
                               int64_t Wo, int epi, void* out, int64_t ldo, const void* add, int64_t ldadd,
                               const void* zero_page, void* stream) {
+    const int variant = 0;
     YUME_REQUIRE(x && W && out && zero_page, "conv3d_cl: NULL pointer");
     YUME_REQUIRE(Tin > 0 && Hin > 0 && Win > 0 && Cin > 0 && Cout > 0 && To > 0 && Ho > 0 && Wo > 0, "conv3d_cl: empty shape");
     YUME_REQUIRE((Cin % 8) == 0 && (ldc % 8) == 0 && ldc >= Cin, "conv3d_cl: Cin=%lld and ldc=%lld must be multiples of 8", (long long)Cin, (long long)ldc);
@@ -121,15 +122,16 @@ extern "C" int yume_conv3d_cl(const void* x, const void* cache, int64_t ldc, int
     e.add = (const unsigned short*)add; e.ldadd = ldadd;
     e.hw = (int)(Ho * Wo);
     hipStream_t s = (hipStream_t)stream;
+    const bool big = use_256(p, variant, true);
     switch (epi) {
-        case YUME_EPI_BF16: return launch<YUME_EPI_BF16>(p, al, e, s, "conv3d_cl");
-        case YUME_EPI_F32: return launch<YUME_EPI_F32>(p, al, e, s, "conv3d_cl");
+        case YUME_EPI_BF16: return big ? launch256<YUME_EPI_BF16>(p, al, e, s, "conv3d_cl") : launch<YUME_EPI_BF16>(p, al, e, s, "conv3d_cl");
+        case YUME_EPI_F32: return big ? launch256<YUME_EPI_F32>(p, al, e, s, "conv3d_cl") : launch<YUME_EPI_F32>(p, al, e, s, "conv3d_cl");
         case YUME_CONV_EPI_ADD:
             YUME_REQUIRE(add != nullptr && (ldadd % 4) == 0, "conv3d_cl: ADD epilogue needs an addend with ldadd %% 4 == 0");
-            return launch<EPI_BF16_ADD>(p, al, e, s, "conv3d_cl");
+            return big ? launch256<EPI_BF16_ADD>(p, al, e, s, "conv3d_cl") : launch<EPI_BF16_ADD>(p, al, e, s, "conv3d_cl");
         case YUME_CONV_EPI_TSPLIT:
             YUME_REQUIRE((Cout % 8) == 0, "conv3d_cl: TSPLIT needs an even channel split");
-            return launch<EPI_BF16_TSPLIT>(p, al, e, s, "conv3d_cl");
+            return big ? launch256<EPI_BF16_TSPLIT>(p, al, e, s, "conv3d_cl") : launch<EPI_BF16_TSPLIT>(p, al, e, s, "conv3d_cl");
         default:
             yume_set_error("conv3d_cl: unknown epilogue %d", epi);
             return YUME_EINVAL;

@@ -8,7 +8,6 @@ extern "C" int yume_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t
                               int64_t N, int64_t K, int epi, void* out, int64_t ldo, const float* gate,
                               int64_t gate_stride, const int32_t* row_idx, void* outT, int64_t ldt, int64_t n_split,
                               int variant, void* stream) {
-    (void)variant;
     YUME_REQUIRE(A && W && out, "gemm_bf16: NULL pointer");
     YUME_REQUIRE(M > 0 && N > 0 && K > 0, "gemm_bf16: empty problem M=%lld N=%lld K=%lld", (long long)M, (long long)N, (long long)K);
     YUME_REQUIRE(M < (1ll << 31) && N < (1ll << 31) && K < (1ll << 31), "gemm_bf16: dimension too large");
@@ -30,19 +29,21 @@ extern "C" int yume_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t
     e.gate = gate; e.gate_stride = gate_stride; e.row_idx = row_idx;
     e.outT = (unsigned short*)outT; e.ldt = ldt; e.n_split = (int)n_split;
     hipStream_t st = (hipStream_t)stream;
+    const bool big = use_256(p, variant, epi != YUME_EPI_BF16_SPLITT || (n_split % 256) == 0);
+#define YUME_GO(E) (big ? launch256<E>(p, al, e, st, "gemm_bf16") : launch<E>(p, al, e, st, "gemm_bf16"))
     switch (epi) {
-        case YUME_EPI_BF16: return launch<YUME_EPI_BF16>(p, al, e, st, "gemm_bf16");
-        case YUME_EPI_BF16_GELU: return launch<YUME_EPI_BF16_GELU>(p, al, e, st, "gemm_bf16");
-        case YUME_EPI_BF16_GELU_ERF: return launch<YUME_EPI_BF16_GELU_ERF>(p, al, e, st, "gemm_bf16");
-        case YUME_EPI_F32: return launch<YUME_EPI_F32>(p, al, e, st, "gemm_bf16");
+        case YUME_EPI_BF16: return YUME_GO(YUME_EPI_BF16);
+        case YUME_EPI_BF16_GELU: return YUME_GO(YUME_EPI_BF16_GELU);
+        case YUME_EPI_BF16_GELU_ERF: return YUME_GO(YUME_EPI_BF16_GELU_ERF);
+        case YUME_EPI_F32: return YUME_GO(YUME_EPI_F32);
         case YUME_EPI_RESID:
             YUME_REQUIRE(gate == nullptr || (gate_stride % 4) == 0, "gemm_bf16: gate_stride must be a multiple of 4");
-            return launch<YUME_EPI_RESID>(p, al, e, st, "gemm_bf16");
+            return YUME_GO(YUME_EPI_RESID);
         case YUME_EPI_BF16_SPLITT:
             YUME_REQUIRE(outT != nullptr && n_split >= 0 && (n_split % BN) == 0 && ldt >= M && (ldt % 4) == 0,
                          "gemm_bf16: SPLITT needs outT, n_split %% 128 == 0, ldt >= M and ldt %% 4 == 0");
             YUME_REQUIRE(((uintptr_t)outT % 16) == 0, "gemm_bf16: outT must be 16-byte aligned");
-            return launch<YUME_EPI_BF16_SPLITT>(p, al, e, st, "gemm_bf16");
+            return YUME_GO(YUME_EPI_BF16_SPLITT);
         default:
             yume_set_error("gemm_bf16: unknown epilogue %d", epi);
             return YUME_EINVAL;

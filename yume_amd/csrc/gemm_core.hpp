@@ -53,10 +53,10 @@ typedef __attribute__((address_space(1))) const void gbl_cvoid;
 struct PlainA {
     const unsigned short* A; int64_t lda; int M;
     const unsigned short* rowp[4];
-    __device__ __forceinline__ void init(int m0, int tid) {
+    __device__ __forceinline__ void init(int m0, int tid, int rpr = 32) {
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
-            const int r = rr * 32 + (tid >> 3);
+            const int r = rr * rpr + (tid >> 3);
             int gr = m0 + r;
             gr = gr < M ? gr : M - 1;
             rowp[rr] = A + (int64_t)gr * lda + (((tid & 7) ^ (r & 7)) << 3);
@@ -94,6 +94,109 @@ __device__ __forceinline__ void stage_a(ALoad& al, int kt, char* lds_tile, int w
 __device__ __forceinline__ bf16x8_t lds_frag(const char* tile, int row, int chunk) {
     const char* p = tile + row * 128 + ((chunk ^ (row & 7)) << 4);
     return *reinterpret_cast<const bf16x8_t*>(p);
+}
+
+// ---- epilogue helpers (shared by the 128^2 and 256^2 kernels) ------------------------------------------------
+// A wave restages a 64x64 fp32 sub-tile through its private 16 KiB of LDS. Staging row r <-> global row m_base + r;
+// staging columns [0,32) <-> global n_base0 + c, [32,64) <-> n_base1 + (c - 32).
+__device__ __forceinline__ void stage_acc(float* ep, const f32x4& a, int i /*16-row block*/, int j /*16-col block*/,
+                                          int lane, bool transposed) {
+    if (!transposed) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ep[(i * 16 + 4 * (lane >> 4) + r) * 64 + j * 16 + (lane & 15)] = a[r];
+    } else {
+        // [n][m] image, 4-float granule g of row n stored at granule g ^ (n & 15)
+        const int n = j * 16 + (lane & 15);
+        const int g = i * 4 + (lane >> 4);
+        *reinterpret_cast<f32x4*>(ep + n * 64 + ((g ^ (n & 15)) << 2)) = a;
+    }
+}
+
+template <int EPI>
+__device__ __forceinline__ void wave_epilogue(const float* ep, bool transposed, const Problem& p, const Epilogue& e,
+                                              int lane, int m_base, int n_base0, int n_base1) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // own LDS writes done (region is private to the wave)
+    __builtin_amdgcn_wave_barrier();
+    const int sub = lane >> 4;         // row within a pass of 4
+    const int c4 = (lane & 15) << 2;   // first of 4 contiguous staging columns
+    if (!transposed) {
+        const int n = (c4 < 32 ? n_base0 : n_base1 - 32) + c4;
+        f32x4 bias4 = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (e.bias && n < p.N) bias4 = *reinterpret_cast<const f32x4*>(e.bias + n);
+#pragma unroll 4
+        for (int ps = 0; ps < 16; ++ps) {
+            const int rl = ps * 4 + sub;
+            const int m = m_base + rl;
+            if (m >= p.M || n >= p.N) continue;
+            f32x4 v = *reinterpret_cast<const f32x4*>(ep + rl * 64 + c4);
+            v += bias4;
+            if (EPI == YUME_EPI_BF16 || EPI == YUME_EPI_BF16_GELU || EPI == YUME_EPI_BF16_SPLITT ||
+                EPI == YUME_EPI_BF16_GELU_ERF || EPI == EPI_BF16_ADD || EPI == EPI_BF16_TSPLIT) {
+                if (EPI == YUME_EPI_BF16_GELU) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) v[q] = gelu_tanh(v[q]);
+                }
+                if (EPI == YUME_EPI_BF16_GELU_ERF) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) v[q] = 0.5f * v[q] * (1.0f + erff(v[q] * 0.7071067811865476f));
+                }
+                if (EPI == EPI_BF16_ADD) {
+                    const u32x2 a2 = *reinterpret_cast<const u32x2*>(e.add + (int64_t)m * e.ldadd + n);
+                    v[0] += bf16_to_f32((unsigned short)(a2[0] & 0xffffu));
+                    v[1] += bf16_to_f32((unsigned short)(a2[0] >> 16));
+                    v[2] += bf16_to_f32((unsigned short)(a2[1] & 0xffffu));
+                    v[3] += bf16_to_f32((unsigned short)(a2[1] >> 16));
+                }
+                u32x2 o;
+                o[0] = pack_bf16x2(v[0], v[1]);
+                o[1] = pack_bf16x2(v[2], v[3]);
+                int64_t orow = m;
+                int ocol = n;
+                if (EPI == EPI_BF16_TSPLIT) {
+                    const int ch = p.N >> 1;
+                    const int j = n >= ch ? 1 : 0;
+                    const int t = m / e.hw;
+                    orow = (int64_t)m + (int64_t)(t + j) * e.hw;   // ((2t + j) * hw + (m - t*hw))
+                    ocol = n - j * ch;
+                }
+                *reinterpret_cast<u32x2*>(reinterpret_cast<unsigned short*>(e.out) + orow * e.ldo + ocol) = o;
+            } else if (EPI == YUME_EPI_F32) {
+                *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(e.out) + (int64_t)m * e.ldo + n) = v;
+            } else {  // YUME_EPI_RESID
+                float* xo = reinterpret_cast<float*>(e.out) + (int64_t)m * e.ldo + n;
+                f32x4 x = *reinterpret_cast<const f32x4*>(xo);
+                if (e.gate) {
+                    const int64_t row = e.row_idx ? (int64_t)e.row_idx[m] : 0;
+                    const f32x4 g = *reinterpret_cast<const f32x4*>(e.gate + row * e.gate_stride + n);
+                    x += v * g;
+                } else {
+                    x += v;
+                }
+                *reinterpret_cast<f32x4*>(xo) = x;
+            }
+        }
+    } else {
+        // rows of the image are output features (staging n), columns are tokens m
+        const int m = m_base + c4;
+#pragma unroll 4
+        for (int ps = 0; ps < 16; ++ps) {
+            const int nl = ps * 4 + sub;
+            const int n = (nl < 32 ? n_base0 : n_base1 - 32) + nl;
+            if (n >= p.N || m >= p.M) continue;
+            const int g = lane & 15;
+            f32x4 v = *reinterpret_cast<const f32x4*>(ep + nl * 64 + ((g ^ (nl & 15)) << 2));
+            const float bn = e.bias ? e.bias[n] : 0.f;
+            unsigned short* dst = e.outT + (int64_t)(n - e.n_split) * e.ldt + m;
+            if (m + 3 < p.M) {
+                u32x2 o;
+                o[0] = pack_bf16x2(v[0] + bn, v[1] + bn);
+                o[1] = pack_bf16x2(v[2] + bn, v[3] + bn);
+                *reinterpret_cast<u32x2*>(dst) = o;
+            } else {
+                for (int q = 0; q < 4 && m + q < p.M; ++q) dst[q] = f32_to_bf16(v[q] + bn);
+            }
+        }
+    }
 }
 
 template <int EPI, class ALoad>
@@ -167,108 +270,241 @@ __global__ __launch_bounds__(NTHR, 2) void gemm128_kernel(Problem p, ALoad al, E
     float* ep = reinterpret_cast<float*>(smem) + wave * (64 * 64);
     const int wm0 = m0 + wm * 64, wn0 = n0 + wn * 64;
     const bool transposed = (EPI == YUME_EPI_BF16_SPLITT) && (n0 >= e.n_split);
-    if (!transposed) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    ep[(i * 16 + 4 * (lane >> 4) + r) * 64 + j * 16 + (lane & 15)] = acc[i][j][r];
-    } else {
-        // [n][m] image, 4-float granule g of row n stored at granule g ^ (n & 15)
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int n = j * 16 + (lane & 15);
-                const int g = i * 4 + (lane >> 4);
-                *reinterpret_cast<f32x4*>(ep + n * 64 + ((g ^ (n & 15)) << 2)) = acc[i][j];
-            }
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // own LDS writes done (region is private to the wave)
-    __builtin_amdgcn_wave_barrier();
+        for (int j = 0; j < 4; ++j) stage_acc(ep, acc[i][j], i, j, lane, transposed);
+    wave_epilogue<EPI>(ep, transposed, p, e, lane, wm0, wn0, wn0 + 32);
+}
 
-    const int sub = lane >> 4;         // row within a pass of 4
-    const int c4 = (lane & 15) << 2;   // first of 4 contiguous columns
-    if (!transposed) {
-        const int n = wn0 + c4;
-        f32x4 bias4 = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (e.bias && n < p.N) bias4 = *reinterpret_cast<const f32x4*>(e.bias + n);
-#pragma unroll 4
-        for (int ps = 0; ps < 16; ++ps) {
-            const int rl = ps * 4 + sub;
-            const int m = wm0 + rl;
-            if (m >= p.M || n >= p.N) continue;
-            f32x4 v = *reinterpret_cast<const f32x4*>(ep + rl * 64 + c4);
-            v += bias4;
-            if (EPI == YUME_EPI_BF16 || EPI == YUME_EPI_BF16_GELU || EPI == YUME_EPI_BF16_SPLITT ||
-                EPI == YUME_EPI_BF16_GELU_ERF || EPI == EPI_BF16_ADD || EPI == EPI_BF16_TSPLIT) {
-                if (EPI == YUME_EPI_BF16_GELU) {
+// =====================================================================================================================
+// 256(M) x 256(N) x 64(K) tile, 512 threads = 8 waves (2 along M x 4 along N), one workgroup per CU, 128 KiB of LDS:
+// two K-tile slots, each made of four 16 KiB HALF-TILES  A0 | A1 | B0 | B1  (128 rows x 64 k).
+// A wave (wr, wc) owns rows {mh*128 + wr*64 + [0,64)} and columns {nh*128 + wc*32 + [0,32)}, mh, nh in {0,1}, so that its
+// (mh, nh) output quadrant reads exactly half-tiles A_mh and B_nh. A K tile is computed in four phases
+//      P1 (0,0): read A0, B0      P2 (0,1): read B1      P3 (1,1): read A1      P4 (1,0): read B0
+// (16 MFMAs each), hence A0 is dead after P1, B1 after P2, A1 after P3, B0 after P4, and each phase re-stages the half-tile
+// that died one phase earlier with the data of two K tiles ahead:
+//      (t,P1): B0(t+1)     (t,P2): A0(t+2)     (t,P3): B1(t+2)     (t,P4): A1(t+2)
+// One s_barrier per phase (after the phase's ds_reads have landed) is what makes the re-staging safe (WAR); the data
+// hazard (RAW) is covered by ONE counted wait per K tile: at (t,P4) `s_waitcnt vmcnt(6)` leaves exactly the three newest
+// half-tiles A0/B1/A1(t+2) in flight and retires everything K tile t+1 needs, and the P4 barrier publishes it to the
+// other waves before anyone reads it in (t+1,P1). Loads therefore stay in flight across barriers for a whole K tile of
+// MFMA work (64 MFMAs per wave) — the LDS-DMA equivalent of a 3-deep cp.async pipeline.
+constexpr int NTHR256 = 512;
+constexpr int HALF_BYTES = 128 * BK * 2;        // 16 KiB
+constexpr int SLOT_BYTES = 4 * HALF_BYTES;      // 64 KiB
+constexpr int LDS256_BYTES = 2 * SLOT_BYTES;    // 128 KiB
+
+template <class ALoad>
+__device__ __forceinline__ void stage_half_a(ALoad& al, int mh, int kt, char* half, int wave) {
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) v[q] = gelu_tanh(v[q]);
-                }
-                if (EPI == YUME_EPI_BF16_GELU_ERF) {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) v[q] = 0.5f * v[q] * (1.0f + erff(v[q] * 0.7071067811865476f));
-                }
-                if (EPI == EPI_BF16_ADD) {
-                    const u32x2 a2 = *reinterpret_cast<const u32x2*>(e.add + (int64_t)m * e.ldadd + n);
-                    v[0] += bf16_to_f32((unsigned short)(a2[0] & 0xffffu));
-                    v[1] += bf16_to_f32((unsigned short)(a2[0] >> 16));
-                    v[2] += bf16_to_f32((unsigned short)(a2[1] & 0xffffu));
-                    v[3] += bf16_to_f32((unsigned short)(a2[1] >> 16));
-                }
-                u32x2 o;
-                o[0] = pack_bf16x2(v[0], v[1]);
-                o[1] = pack_bf16x2(v[2], v[3]);
-                int64_t orow = m;
-                int ocol = n;
-                if (EPI == EPI_BF16_TSPLIT) {
-                    const int ch = p.N >> 1;
-                    const int j = n >= ch ? 1 : 0;
-                    const int t = m / e.hw;
-                    orow = (int64_t)m + (int64_t)(t + j) * e.hw;   // ((2t + j) * hw + (m - t*hw))
-                    ocol = n - j * ch;
-                }
-                *reinterpret_cast<u32x2*>(reinterpret_cast<unsigned short*>(e.out) + orow * e.ldo + ocol) = o;
-            } else if (EPI == YUME_EPI_F32) {
-                *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(e.out) + (int64_t)m * e.ldo + n) = v;
-            } else {  // YUME_EPI_RESID
-                float* xo = reinterpret_cast<float*>(e.out) + (int64_t)m * e.ldo + n;
-                f32x4 x = *reinterpret_cast<const f32x4*>(xo);
-                if (e.gate) {
-                    const int64_t row = e.row_idx ? (int64_t)e.row_idx[m] : 0;
-                    const f32x4 g = *reinterpret_cast<const f32x4*>(e.gate + row * e.gate_stride + n);
-                    x += v * g;
-                } else {
-                    x += v;
-                }
-                *reinterpret_cast<f32x4*>(xo) = x;
-            }
-        }
-    } else {
-        // rows of the image are output features n, columns are tokens m
-        const int m = wm0 + c4;
-#pragma unroll 4
-        for (int ps = 0; ps < 16; ++ps) {
-            const int nl = ps * 4 + sub;
-            const int n = wn0 + nl;
-            if (n >= p.N || m >= p.M) continue;
-            const int g = lane & 15;
-            f32x4 v = *reinterpret_cast<const f32x4*>(ep + nl * 64 + ((g ^ (nl & 15)) << 2));
-            const float bn = e.bias ? e.bias[n] : 0.f;
-            unsigned short* dst = e.outT + (int64_t)(n - e.n_split) * e.ldt + m;
-            if (m + 3 < p.M) {
-                u32x2 o;
-                o[0] = pack_bf16x2(v[0] + bn, v[1] + bn);
-                o[1] = pack_bf16x2(v[2] + bn, v[3] + bn);
-                *reinterpret_cast<u32x2*>(dst) = o;
-            } else {
-                for (int q = 0; q < 4 && m + q < p.M; ++q) dst[q] = f32_to_bf16(v[q] + bn);
-            }
-        }
+    for (int r2 = 0; r2 < 2; ++r2) {
+        const unsigned short* g = al.src(mh * 2 + r2, kt);
+        char* l = half + r2 * 8192 + wave * 1024;
+        __builtin_amdgcn_global_load_lds((gbl_cvoid*)g, (lds_void*)l, 16, 0, 0);
     }
+}
+
+__device__ __forceinline__ void stage_half_b(const unsigned short* const (&wrow)[4], int nh, int kt, char* half, int wave) {
+#pragma unroll
+    for (int r2 = 0; r2 < 2; ++r2) {
+        const unsigned short* g = wrow[nh * 2 + r2] + kt * BK;
+        char* l = half + r2 * 8192 + wave * 1024;
+        __builtin_amdgcn_global_load_lds((gbl_cvoid*)g, (lds_void*)l, 16, 0, 0);
+    }
+}
+
+#define YUME_PHASE_SYNC()                                   \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      \
+    __builtin_amdgcn_s_barrier();                           \
+    __builtin_amdgcn_sched_barrier(0)
+
+template <int EPI, class ALoad>
+__global__ __launch_bounds__(NTHR256, 2) void gemm256_kernel(Problem p, ALoad al, Epilogue e) {
+    __shared__ __attribute__((aligned(16))) char smem[LDS256_BYTES];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+
+    // ---- workgroup -> tile (XCD-aware, grouped) ----
+    const int nwg = p.tiles_m * p.tiles_n;
+    int wg;
+    {
+        const int bid = blockIdx.x;
+        const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+        wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    constexpr int GROUP_M = 4;
+    const int width = GROUP_M * p.tiles_n;
+    const int group = wg / width;
+    const int first_m = group * GROUP_M;
+    const int gsz = min(p.tiles_m - first_m, GROUP_M);
+    const int tm = first_m + (wg % width) % gsz;
+    const int tn = (wg % width) / gsz;
+    const int m0 = tm * 256, n0 = tn * 256;
+
+    // W rows of this thread: half-tile nh, round r2 -> row nh*128 + r2*64 + tid/8 (clamped), source chunk swizzled
+    const unsigned short* wrow[4];
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+        const int r = rr * 64 + (tid >> 3);
+        int gr = n0 + r;
+        gr = gr < p.N ? gr : p.N - 1;
+        wrow[rr] = p.W + (int64_t)gr * p.ldw + (((tid & 7) ^ (r & 7)) << 3);
+    }
+    al.init(m0, tid, 64);
+
+    f32x4 acc[2][2][4][2];   // [mh][nh][mi][ni]
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[a][b][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = p.K / BK;
+    char* const s0 = smem;
+    char* const s1 = smem + SLOT_BYTES;
+    // half-tile offsets inside a slot
+    constexpr int OA0 = 0, OA1 = HALF_BYTES, OB0 = 2 * HALF_BYTES, OB1 = 3 * HALF_BYTES;
+
+    // ---- prologue: issue order = steady-state order (A0, B1, A1, B0 of tile 0; A0, B1, A1 of tile 1) ----
+    stage_half_a(al, 0, 0, s0 + OA0, wave);
+    stage_half_b(wrow, 1, 0, s0 + OB1, wave);
+    stage_half_a(al, 1, 0, s0 + OA1, wave);
+    al.advance();
+    stage_half_b(wrow, 0, 0, s0 + OB0, wave);
+    if (nk > 1) {
+        stage_half_a(al, 0, 1, s1 + OA0, wave);
+        stage_half_b(wrow, 1, 1, s1 + OB1, wave);
+        stage_half_a(al, 1, 1, s1 + OA1, wave);
+        al.advance();
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+
+    const int arow = wr * 64 + (lane & 15);   // + mi*16 : row inside half-tile A_mh
+    const int brow = wc * 32 + (lane & 15);   // + ni*16 : row inside half-tile B_nh
+    const int lch = lane >> 4;                // + ks*4  : logical 16-byte chunk
+
+    for (int t = 0; t < nk; ++t) {
+        char* cs = (t & 1) ? s1 : s0;          // slot of K tile t (and t+2)
+        char* ns = (t & 1) ? s0 : s1;          // slot of K tile t+1
+        bf16x8_t a[4][2], b[2][2];             // [mi][ks], [ni][ks]
+
+        // ---------------- P1: quadrant (0,0) ----------------
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) b[ni][ks] = lds_frag(cs + OB0, brow + ni * 16, ks * 4 + lch);
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) a[mi][ks] = lds_frag(cs + OA0, arow + mi * 16, ks * 4 + lch);
+        if (t + 1 < nk) stage_half_b(wrow, 0, t + 1, ns + OB0, wave);
+        YUME_PHASE_SYNC();
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+                    acc[0][0][mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mi][ks], b[ni][ks], acc[0][0][mi][ni], 0, 0, 0);
+
+        // ---------------- P2: quadrant (0,1) ----------------
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) b[ni][ks] = lds_frag(cs + OB1, brow + ni * 16, ks * 4 + lch);
+        if (t + 2 < nk) stage_half_a(al, 0, t + 2, cs + OA0, wave);
+        YUME_PHASE_SYNC();
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+                    acc[0][1][mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mi][ks], b[ni][ks], acc[0][1][mi][ni], 0, 0, 0);
+
+        // ---------------- P3: quadrant (1,1) ----------------
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) a[mi][ks] = lds_frag(cs + OA1, arow + mi * 16, ks * 4 + lch);
+        if (t + 2 < nk) stage_half_b(wrow, 1, t + 2, cs + OB1, wave);
+        YUME_PHASE_SYNC();
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+                    acc[1][1][mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mi][ks], b[ni][ks], acc[1][1][mi][ni], 0, 0, 0);
+
+        // ---------------- P4: quadrant (1,0) ----------------
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) b[ni][ks] = lds_frag(cs + OB0, brow + ni * 16, ks * 4 + lch);
+        if (t + 2 < nk) {
+            stage_half_a(al, 1, t + 2, cs + OA1, wave);
+            al.advance();
+            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // K tile t+1 complete; A0/B1/A1(t+2) stay in flight
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        YUME_PHASE_SYNC();
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+                    acc[1][0][mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mi][ks], b[ni][ks], acc[1][0][mi][ni], 0, 0, 0);
+    }
+
+    // ---- epilogue: every LDS read finished before the last barrier; each wave restages its two 64x64 halves
+    //      through its private 16 KiB and stores them with the fused epilogue ----
+    float* ep = reinterpret_cast<float*>(smem) + wave * (64 * 64);
+    const bool transposed = (EPI == YUME_EPI_BF16_SPLITT) && (n0 >= e.n_split);
+#pragma unroll
+    for (int mh = 0; mh < 2; ++mh) {
+#pragma unroll
+        for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) stage_acc(ep, acc[mh][nh][mi][ni], mi, nh * 2 + ni, lane, transposed);
+        wave_epilogue<EPI>(ep, transposed, p, e, lane, m0 + mh * 128 + wr * 64, n0 + wc * 32, n0 + 128 + wc * 32);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // staging reads done before the next half overwrites it
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+template <int EPI, class ALoad>
+int launch256(const Problem& p128, const ALoad& al, const Epilogue& e, hipStream_t st, const char* what) {
+    Problem p = p128;
+    p.tiles_m = (p.M + 255) / 256;
+    p.tiles_n = (p.N + 255) / 256;
+    dim3 grid((unsigned)(p.tiles_m * p.tiles_n)), block(NTHR256);
+    hipLaunchKernelGGL((gemm256_kernel<EPI, ALoad>), grid, block, 0, st, p, al, e);
+    YUME_CHECK_LAUNCH(what);
+    return YUME_OK;
+}
+
+// kernel selection: variant 1 = 128^2 tile, 2 = 256^2 tile, 0 = automatic (256^2 once it fills the chip)
+inline bool use_256(const Problem& p, int variant, bool split_ok) {
+    if (variant == 1 || !split_ok) return false;
+    if (variant == 2) return true;
+    const int64_t t256 = (int64_t)((p.M + 255) / 256) * ((p.N + 255) / 256);
+    return t256 >= 192;
 }
 
 template <int EPI, class ALoad>
