@@ -164,30 +164,32 @@ def attn_ref(q, k, v, scale):
     return (a @ vd).transpose(0, 1)                                     # [Lq, H, D]
 
 
-def run_attn(q, k, v, scale=None, accumulate=None):
+def run_attn(q, k, v, scale=None, accumulate=None, variant=0):
     Lq, H, D = q.shape
     Lk = k.shape[0]
     vt = torch.empty(H * D, (Lk + 7) // 8 * 8, dtype=torch.bfloat16, device=DEV).fill_(float("nan"))
     ops.transpose_bf16(v.reshape(Lk, H * D).to(DEV), vt)
     out = torch.empty(Lq, H * D, dtype=torch.bfloat16, device=DEV) if accumulate is None else accumulate
     ops.attn_fwd(q.reshape(Lq, H * D).to(DEV), k.reshape(Lk, H * D).to(DEV), vt, out, Lq, Lk, H, scale=scale,
-                 accumulate=accumulate is not None)
+                 accumulate=accumulate is not None, variant=variant)
     return out.cpu().view(Lq, H, D)
 
 
 @pytest.mark.parametrize("Lq,Lk,H", [(128, 64, 1), (32, 128, 2), (300, 300, 3), (1000, 512, 4), (517, 257, 2), (2048, 2048, 8),
-                                     (64, 1, 1), (1, 77, 3), (130, 1000, 24)])
-def test_attention_matches_exact_softmax(Lq, Lk, H):
+                                     (64, 1, 1), (1, 77, 3), (130, 1000, 24), (200, 640, 2), (100, 65, 1)])
+@pytest.mark.parametrize("variant", [1, 2])
+def test_attention_matches_exact_softmax(Lq, Lk, H, variant):
     q, k, v = (rnd(L, H, 128, seed=s, dtype=torch.bfloat16) for L, s in ((Lq, 1), (Lk, 2), (Lk, 3)))
     want = attn_ref(q, k, v, 1 / math.sqrt(128))
-    got = run_attn(q, k, v)
+    got = run_attn(q, k, v, variant=variant)
     assert torch.isfinite(got).all()
     # P is rounded to bf16 before PV (as flash-attn does): max-abs 2^-7 of the value scale, rel-L2 well below bf16 eps
     assert (got.double() - want).abs().max() <= 1.5e-2 * max(want.abs().max().item(), 1e-3)
     assert rel_l2(got, want) < 6e-3
 
 
-def test_attention_rescale_branch_and_scale():
+@pytest.mark.parametrize("variant", [1, 2])
+def test_attention_rescale_branch_and_scale(variant):
     """a key that spikes late forces the running max to jump (online-softmax rescale) in a chosen tile."""
     Lq, Lk, H = 96, 640, 2
     q, k, v = (rnd(L, H, 128, seed=s, dtype=torch.bfloat16) for L, s in ((Lq, 4), (Lk, 5), (Lk, 6)))
@@ -195,15 +197,16 @@ def test_attention_rescale_branch_and_scale():
     k[5] = (q[40].float() * 3).to(torch.bfloat16)
     for scale in (1 / math.sqrt(128), 0.3):
         want = attn_ref(q, k, v, scale)
-        got = run_attn(q, k, v, scale=scale)
+        got = run_attn(q, k, v, scale=scale, variant=variant)
         assert (got.double() - want).abs().max() <= 2e-2 * want.abs().max()
 
 
-def test_attention_accumulate_and_transposed_operand():
+@pytest.mark.parametrize("variant", [1, 2])
+def test_attention_accumulate_and_transposed_operand(variant):
     Lq, Lk, H = 200, 257, 2
     q, k, v = (rnd(L, H, 128, seed=s, dtype=torch.bfloat16) for L, s in ((Lq, 7), (Lk, 8), (Lk, 9)))
     base = rnd(Lq, H * 128, seed=10, dtype=torch.bfloat16)
-    got = run_attn(q, k, v, accumulate=base.to(DEV).clone())
+    got = run_attn(q, k, v, accumulate=base.to(DEV).clone(), variant=variant)
     want = attn_ref(q, k, v, 1 / math.sqrt(128)) + base.view(Lq, H, 128).double()
     assert (got.double() - want).abs().max() <= 2e-2 * want.abs().max()
     # asymmetric V (value = its own key index in d=0, head index in d=1) catches key/head permutations
@@ -211,7 +214,7 @@ def test_attention_accumulate_and_transposed_operand():
     v2[:, :, 0] = torch.arange(Lk).view(Lk, 1) / 64.0
     v2[:, :, 1] = torch.arange(H).view(1, H) + 1.0
     v2 = v2.to(torch.bfloat16)
-    got = run_attn(q, k, v2)
+    got = run_attn(q, k, v2, variant=variant)
     want = attn_ref(q, k, v2, 1 / math.sqrt(128))
     assert (got.double() - want).abs().max() <= 2e-2 * want.abs().max()
 

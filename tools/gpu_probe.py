@@ -70,10 +70,11 @@ def main():
         q, k = bf(Lq, Cc), bf(Lk, Cc)
         vtt = bf(Cc, (Lk + 7) // 8 * 8)
         o = torch.empty(Lq, Cc, dtype=torch.bfloat16, device=DEV)
-        ms = timeit(lambda: ops.attn_fwd(q, k, vtt, o, Lq, Lk, Hh), warm=1, iters=3)
         fl = 4 * Lq * Lk * Cc
-        res[f"attn_{tag}"] = {"ms": ms, "tflops": fl / ms / 1e9}
-        print(f"attn {tag} Lq={Lq} Lk={Lk} H={Hh}: {ms:.3f} ms {fl/ms/1e9:.0f} TF", flush=True)
+        for av in (1, 2):
+            ms = timeit(lambda: ops.attn_fwd(q, k, vtt, o, Lq, Lk, Hh, variant=av), warm=1, iters=3)
+            res[f"attn_{tag}_v{av}"] = {"ms": ms, "tflops": fl / ms / 1e9}
+            print(f"attn {tag} v{av} Lq={Lq} Lk={Lk} H={Hh}: {ms:.3f} ms {fl/ms/1e9:.0f} TF", flush=True)
         del q, k, vtt, o
     # ---- HBM-bound kernels
     xs = torch.randn(L, C, device=DEV)

@@ -282,12 +282,235 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(AttnArgs p) {
     }
 }
 
+// =====================================================================================================================
+// v2: same math and tile shapes, different data movement.
+//   * K and V^T tiles go HBM -> LDS by LDS-DMA (global_load_lds_dwordx4): no staging VGPRs, no ds_write pass; the
+//     bank swizzles are applied on the per-lane SOURCE address (K: chunk ^ (row & 15); V^T: chunk ^ ((row >> 1) & 7))
+//     so both tiles are read with conflict-free ds_read_b128.
+//   * V^T fragments are 16 contiguous bytes = 8 CONSECUTIVE keys, so the P operand has to hold 8 consecutive keys too:
+//     after the exp the packed P words of the two half-waves are exchanged with 8 v_permlane32_swap per tile
+//     (lane (q,0) gives its odd 4-key groups, receives the partner's even ones).
+//   * only a ragged last tile (Lk % 64 != 0) is register-staged, to zero the keys >= Lk of V^T.
+// The DMA of tile t+1 is issued before the compute of tile t and waited for (vmcnt(0)) right before the single
+// per-tile barrier, i.e. it has the whole tile of MFMA work to land.
+constexpr int V2_BUF = 2 * K_TILE_BYTES;      // K 16 KiB + V^T 16 KiB (128-byte rows, no padding)
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) const void gbl_cvoid_t;
+
+__device__ __forceinline__ void dma_tile(const AttnArgs& p, int h, int j0, char* buf, int tid, int wave) {
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {          // K: 64 rows x 16 chunks
+        const int r = rr * 16 + (tid >> 4);
+        int key = j0 + r;
+        key = key < p.Lk ? key : p.Lk - 1;
+        const unsigned short* g = p.K + (int64_t)key * p.ldk + h * D + (((tid & 15) ^ (r & 15)) << 3);
+        __builtin_amdgcn_global_load_lds((gbl_cvoid_t*)g, (lds_void_t*)(buf + rr * 4096 + wave * 1024), 16, 0, 0);
+    }
+    char* vb = buf + K_TILE_BYTES;
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {          // V^T: 128 rows x 8 chunks
+        const int d = rr * 32 + (tid >> 3);
+        const unsigned short* g = p.Vt + (int64_t)(h * D + d) * p.ldvt + j0 + (((tid & 7) ^ ((d >> 1) & 7)) << 3);
+        __builtin_amdgcn_global_load_lds((gbl_cvoid_t*)g, (lds_void_t*)(vb + rr * 4096 + wave * 1024), 16, 0, 0);
+    }
+}
+
+// register path for the ragged last tile: same LDS image as dma_tile, keys >= Lk of V^T zeroed (stage_load does it)
+__device__ __forceinline__ void stage_store_v2(const Stage& s, char* buf, int tid) {
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+        const int r = (tid >> 4) + 16 * rr;
+        *reinterpret_cast<u32x4*>(buf + r * 256 + (((tid & 15) ^ (r & 15)) << 4)) = s.k[rr];
+    }
+    char* vb = buf + K_TILE_BYTES;
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+        const int d = (tid >> 3) + 32 * rr;
+        *reinterpret_cast<u32x4*>(vb + d * 128 + (((tid & 7) ^ ((d >> 1) & 7)) << 4)) = s.v[rr];
+    }
+}
+
+template <bool MASK>
+__device__ __forceinline__ void tile_body_v2(const char* kb, const AttnArgs& p, const bf16x8_t (&qf)[8],
+                                             f32x16 (&oacc)[4], float& m_run, float& l_run, int j0, int ql, int hi) {
+    const char* vb = kb + K_TILE_BYTES;
+    f32x16 sacc[2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sacc[b][r] = 0.f;
+        const int row = 32 * b + ql;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            const int c = 2 * ks + hi;
+            const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(kb + row * 256 + ((c ^ (row & 15)) << 4));
+            sacc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sacc[b], 0, 0, 0);
+        }
+    }
+    // rows >= Lk of the K tile are clamped copies of key Lk-1, so the row max needs no mask; their P is zeroed below
+    float mx = sacc[0][0];
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[b][r]);
+    mx = xhalf_max(mx);
+    const float m_new = fmaxf(m_run, mx * p.scale_log2);
+    if (!__all(m_new - m_run <= DEFER_LOG2)) {
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+        m_run = m_new;
+        l_run *= alpha;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
+    }
+    float psum = 0.f;
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float pv = __builtin_amdgcn_exp2f(fmaf(sacc[b][r], p.scale_log2, -m_run));
+            if (MASK) {
+                const int key = j0 + 32 * b + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                pv = key < p.Lk ? pv : 0.f;
+            }
+            sacc[b][r] = pv;
+            psum += pv;
+        }
+    l_run += psum;
+
+    // ---- P^T fragments of 8 consecutive keys: k-step sg = 2b+e covers keys 16*sg + 8*hi' + j ----
+    bf16x8_t pf[4];
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            u32x4 w;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const unsigned ev = pack_bf16x2(sacc[b][8 * e + 2 * i], sacc[b][8 * e + 2 * i + 1]);          // group 2e
+                const unsigned od = pack_bf16x2(sacc[b][8 * e + 4 + 2 * i], sacc[b][8 * e + 4 + 2 * i + 1]);  // group 2e+1
+                const auto r = __builtin_amdgcn_permlane32_swap(ev, od, false, false);
+                w[i] = r[0];        // keys j = 0..3 of this lane's half
+                w[2 + i] = r[1];    // keys j = 4..7
+            }
+            pf[2 * b + e] = __builtin_bit_cast(bf16x8_t, w);
+        }
+
+    // ---- O^T += V^T . P^T ----
+#pragma unroll
+    for (int db = 0; db < 4; ++db) {
+        const int d = 32 * db + ql;
+        const char* vrow = vb + d * 128;
+        const int sw = (d >> 1) & 7;
+#pragma unroll
+        for (int sg = 0; sg < 4; ++sg) {
+            const bf16x8_t vf = *reinterpret_cast<const bf16x8_t*>(vrow + (((2 * sg + hi) ^ sw) << 4));
+            oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[sg], oacc[db], 0, 0, 0);
+        }
+    }
+}
+
+__global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel_v2(AttnArgs p) {
+    __shared__ __attribute__((aligned(16))) char smem[2 * V2_BUF];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int hi = lane >> 5;
+    const int ql = lane & 31;
+    int h, qb;
+    {
+        const int bid = blockIdx.x;
+        const int xcd = bid & 7, idx = bid >> 3;
+        const int hx = (p.H + 7 - xcd) >> 3;
+        const int per = hx * p.nqb;
+        if (idx >= per) return;
+        h = xcd + 8 * (idx / p.nqb);
+        qb = idx % p.nqb;
+    }
+    const int q0 = qb * QB + wave * QW;
+    bf16x8_t qf[8];
+    {
+        int q = q0 + ql;
+        q = q < p.Lq ? q : p.Lq - 1;
+        const unsigned short* qp = p.Q + (int64_t)q * p.ldq + h * D + 8 * hi;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) qf[ks] = *reinterpret_cast<const bf16x8_t*>(qp + 16 * ks);
+    }
+    f32x16 oacc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[i][r] = 0.f;
+    float m_run = NEG_BIG, l_run = 0.f;
+
+    const int nt = (p.Lk + KT - 1) / KT;
+    const bool ragged = (p.Lk % KT) != 0;          // then the LAST tile takes the register path
+    if (nt == 1 && ragged) {
+        Stage st;
+        stage_load(st, p, h, 0, tid);
+        stage_store_v2(st, smem, tid);
+    } else {
+        dma_tile(p, h, 0, smem, tid, wave);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    int cur = 0;
+    for (int t = 0; t < nt; ++t) {
+        char* kb = smem + cur * V2_BUF;
+        char* nb = smem + (cur ^ 1) * V2_BUF;
+        const bool has_next = t + 1 < nt;
+        const bool next_reg = has_next && ragged && (t + 2 == nt);
+        if (has_next && !next_reg) dma_tile(p, h, (t + 1) * KT, nb, tid, wave);
+        if (!has_next && ragged)
+            tile_body_v2<true>(kb, p, qf, oacc, m_run, l_run, t * KT, ql, hi);
+        else
+            tile_body_v2<false>(kb, p, qf, oacc, m_run, l_run, t * KT, ql, hi);
+        if (next_reg) {
+            Stage st;
+            stage_load(st, p, h, (t + 1) * KT, tid);
+            stage_store_v2(st, nb, tid);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    const float l_tot = xhalf_sum(l_run);
+    const float inv = 1.0f / l_tot;
+    const int q = q0 + ql;
+    if (q < p.Lq) {
+        unsigned short* op = p.O + (int64_t)q * p.ldo + h * D + 4 * hi;
+#pragma unroll
+        for (int db = 0; db < 4; ++db)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float v0 = oacc[db][4 * g + 0] * inv, v1 = oacc[db][4 * g + 1] * inv;
+                float v2 = oacc[db][4 * g + 2] * inv, v3 = oacc[db][4 * g + 3] * inv;
+                u32x2* dst = reinterpret_cast<u32x2*>(op + 32 * db + 8 * g);
+                if (p.accumulate) {
+                    const u32x2 old = *dst;
+                    v0 += bf16_to_f32((unsigned short)(old[0] & 0xffffu));
+                    v1 += bf16_to_f32((unsigned short)(old[0] >> 16));
+                    v2 += bf16_to_f32((unsigned short)(old[1] & 0xffffu));
+                    v3 += bf16_to_f32((unsigned short)(old[1] >> 16));
+                }
+                u32x2 o;
+                o[0] = pack_bf16x2(v0, v1);
+                o[1] = pack_bf16x2(v2, v3);
+                *dst = o;
+            }
+    }
+}
+
 }  // namespace
+
 
 extern "C" int yume_attn_fwd(const void* Q, int64_t ldq, const void* K, int64_t ldk, const void* Vt, int64_t ldvt,
                              void* O, int64_t ldo, int64_t Lq, int64_t Lk, int64_t H, float scale, int accumulate,
                              int variant, void* stream) {
-    (void)variant;
     YUME_REQUIRE(Q && K && Vt && O, "attn_fwd: NULL pointer");
     YUME_REQUIRE(Lq > 0 && Lk > 0 && H > 0, "attn_fwd: empty problem Lq=%lld Lk=%lld H=%lld", (long long)Lq, (long long)Lk, (long long)H);
     YUME_REQUIRE(Lq < (1ll << 30) && Lk < (1ll << 30) && H < 65536, "attn_fwd: dimension too large");
@@ -306,7 +529,10 @@ extern "C" int yume_attn_fwd(const void* Q, int64_t ldq, const void* K, int64_t 
     // every XCD slot gets ceil(H/8)*nqb block ids; surplus ids exit immediately
     const int64_t per_xcd = ((H + 7) / 8) * a.nqb;
     dim3 grid((unsigned)(per_xcd * 8)), block(NW * 64);
-    hipLaunchKernelGGL(attn_fwd_kernel, grid, block, 0, (hipStream_t)stream, a);
+    if (variant == 1)
+        hipLaunchKernelGGL(attn_fwd_kernel, grid, block, 0, (hipStream_t)stream, a);
+    else
+        hipLaunchKernelGGL(attn_fwd_kernel_v2, grid, block, 0, (hipStream_t)stream, a);
     YUME_CHECK_LAUNCH("attn_fwd");
     return YUME_OK;
 }

@@ -15,6 +15,7 @@
 // blocks resident on one XCD share A row-panels and W column-panels in that XCD's L2.
 #pragma once
 #include "common.hpp"
+#include <stdlib.h>
 
 namespace gemm_core {
 
@@ -318,9 +319,12 @@ __device__ __forceinline__ void stage_half_b(const unsigned short* const (&wrow)
 #define YUME_PHASE_SYNC()                                   \
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      \
     __builtin_amdgcn_s_barrier();                           \
-    __builtin_amdgcn_sched_barrier(0)
+    __builtin_amdgcn_sched_barrier(0);                      \
+    if (PRIO) __builtin_amdgcn_s_setprio(1)
+#define YUME_PHASE_END() \
+    if (PRIO) __builtin_amdgcn_s_setprio(0)
 
-template <int EPI, class ALoad>
+template <int EPI, class ALoad, bool PRIO = true>
 __global__ __launch_bounds__(NTHR256, 2) void gemm256_kernel(Problem p, ALoad al, Epilogue e) {
     __shared__ __attribute__((aligned(16))) char smem[LDS256_BYTES];
     const int tid = threadIdx.x;
@@ -417,6 +421,7 @@ __global__ __launch_bounds__(NTHR256, 2) void gemm256_kernel(Problem p, ALoad al
 #pragma unroll
                 for (int ni = 0; ni < 2; ++ni)
                     acc[0][0][mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mi][ks], b[ni][ks], acc[0][0][mi][ni], 0, 0, 0);
+        YUME_PHASE_END();
 
         // ---------------- P2: quadrant (0,1) ----------------
 #pragma unroll
@@ -432,6 +437,7 @@ __global__ __launch_bounds__(NTHR256, 2) void gemm256_kernel(Problem p, ALoad al
 #pragma unroll
                 for (int ni = 0; ni < 2; ++ni)
                     acc[0][1][mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mi][ks], b[ni][ks], acc[0][1][mi][ni], 0, 0, 0);
+        YUME_PHASE_END();
 
         // ---------------- P3: quadrant (1,1) ----------------
 #pragma unroll
@@ -447,6 +453,7 @@ __global__ __launch_bounds__(NTHR256, 2) void gemm256_kernel(Problem p, ALoad al
 #pragma unroll
                 for (int ni = 0; ni < 2; ++ni)
                     acc[1][1][mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mi][ks], b[ni][ks], acc[1][1][mi][ni], 0, 0, 0);
+        YUME_PHASE_END();
 
         // ---------------- P4: quadrant (1,0) ----------------
 #pragma unroll
@@ -468,6 +475,7 @@ __global__ __launch_bounds__(NTHR256, 2) void gemm256_kernel(Problem p, ALoad al
 #pragma unroll
                 for (int ni = 0; ni < 2; ++ni)
                     acc[1][0][mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mi][ks], b[ni][ks], acc[1][0][mi][ni], 0, 0, 0);
+        YUME_PHASE_END();
     }
 
     // ---- epilogue: every LDS read finished before the last barrier; each wave restages its two 64x64 halves
@@ -488,13 +496,23 @@ __global__ __launch_bounds__(NTHR256, 2) void gemm256_kernel(Problem p, ALoad al
     }
 }
 
+// A/B switch for the s_setprio(1) bracket around each phase's MFMA cluster (env YUME_GEMM_PRIO=0 disables)
+inline bool read_prio_env() {
+    const char* v = getenv("YUME_GEMM_PRIO");
+    return !(v && v[0] == '0');
+}
+static const bool g_prio256 = read_prio_env();
+
 template <int EPI, class ALoad>
 int launch256(const Problem& p128, const ALoad& al, const Epilogue& e, hipStream_t st, const char* what) {
     Problem p = p128;
     p.tiles_m = (p.M + 255) / 256;
     p.tiles_n = (p.N + 255) / 256;
     dim3 grid((unsigned)(p.tiles_m * p.tiles_n)), block(NTHR256);
-    hipLaunchKernelGGL((gemm256_kernel<EPI, ALoad>), grid, block, 0, st, p, al, e);
+    if (g_prio256)
+        hipLaunchKernelGGL((gemm256_kernel<EPI, ALoad, true>), grid, block, 0, st, p, al, e);
+    else
+        hipLaunchKernelGGL((gemm256_kernel<EPI, ALoad, false>), grid, block, 0, st, p, al, e);
     YUME_CHECK_LAUNCH(what);
     return YUME_OK;
 }
