@@ -1,0 +1,108 @@
+"""TEST INFRASTRUCTURE — CPU restatement of the reference's denoise loops, kept deliberately close to the scripts'
+own variable flow so it is an independent check of yume_amd/sampling.py:
+
+  euler_5b    fastvideo/sample/sample_5b.py:942-1034   (clean history, one forward per step)
+  euler_14b   fastvideo/sample/sample.py:745-790       (CFG 5.0, history re-noised with sigma_{i+1})
+  tts         fastvideo/sample/sample_tts.py:694-868   (SDE eta 0.3, time travel step 2 / interval 2 / repeat 1)
+
+`transformer(latent, sigma_index, which)` stands for the model call (which in {"cond","uncond"}) and returns the velocity
+for the whole latent; `randn(shape)` stands for torch.randn_like so tests can replay the same noise.
+"""
+import math
+
+import numpy as np
+import torch
+
+
+def get_sampling_sigmas(sampling_steps, shift):
+    """sample_5b.py:502-506 (numpy, float64)."""
+    sigma = np.linspace(1, 0, sampling_steps + 1)[:sampling_steps]
+    return (shift * sigma / (1 + (shift - 1) * sigma))
+
+
+def euler_5b(transformer, latent, model_input, sigmas, lfz):
+    S = len(sigmas)
+    for i in range(S):
+        pred = transformer(latent, i, "cond")
+        if i + 1 == S:
+            temp_x0 = latent[:, -lfz:] + (0 - sigmas[i]) * pred[:, -lfz:]
+        else:
+            temp_x0 = latent[:, -lfz:] + (sigmas[i + 1] - sigmas[i]) * pred[:, -lfz:]
+        latent = torch.cat([model_input[:, :-lfz], temp_x0], dim=1)
+    return latent
+
+
+def euler_14b(transformer, latent, model_input, noise, sigmas, lfz, guide=5.0):
+    S = len(sigmas)
+    for i in range(S):
+        cond = transformer(latent, i, "cond")
+        uncond = transformer(latent, i, "uncond")
+        pred = uncond + guide * (cond - uncond)
+        if i + 1 == S:
+            temp_x0 = latent[:, -lfz:] + (0 - sigmas[i]) * pred[:, -lfz:]
+        else:
+            temp_x0 = latent[:, -lfz:] + (sigmas[i + 1] - sigmas[i]) * pred[:, -lfz:]
+        index1 = min(S - 1, i + 1)
+        latent = torch.cat([noise[:, :-lfz] * sigmas[index1] + (1 - sigmas[index1]) * model_input[:, :-lfz], temp_x0], dim=1)
+    return latent
+
+
+def tts(transformer, latent, model_input, noise, sigmas, lfz, randn, sde=True, guide=5.0, cfg=True, renoise=True):
+    """sample_tts.py:694-868. cfg/renoise=False give the BASELINE config-4 composition (5B model: no CFG, clean history)."""
+    S = len(sigmas)
+    time_travel_step, time_travel_interval = 2, 2
+    current_pred = None
+
+    def hist(idx):
+        if renoise:
+            return noise[:, :-lfz] * sigmas[idx] + (1 - sigmas[idx]) * model_input[:, :-lfz]
+        return model_input[:, :-lfz]
+
+    def velocity(lat, idx):
+        c = transformer(lat, idx, "cond")
+        if not cfg:
+            return c
+        u = transformer(lat, idx, "uncond")
+        return u + guide * (c - u)
+
+    for i in range(S):
+        pred = velocity(latent, i)
+        nxt = 0 if i + 1 == S else sigmas[i + 1]
+        temp_x0 = latent[:, -lfz:] + (nxt - sigmas[i]) * pred[:, -lfz:]
+        if sde:
+            prev_sample_mean = temp_x0
+            pred_original_sample = latent[:, -lfz:] + (0 - sigmas[i]) * pred[:, -lfz:]
+            eta = 0.3
+            last50 = (i + 1 == 50)
+            delta_t = 0 if last50 else (sigmas[i] - nxt)
+            if delta_t < 0:
+                delta_t = 0
+            dsigma = (0 - sigmas[i]) if last50 else (nxt - sigmas[i])
+            std_dev_t = eta * math.sqrt(delta_t)
+            score_estimate = -(latent[:, -lfz:] - pred_original_sample * (1 - sigmas[i])) / sigmas[i] ** 2
+            log_term = -0.5 * eta ** 2 * score_estimate
+            prev_sample_mean = prev_sample_mean + log_term * dsigma
+            temp_x0 = prev_sample_mean + randn(prev_sample_mean.shape) * std_dev_t
+        if time_travel_interval > 0 and i % time_travel_interval == 0:
+            travel_step = min(S - 1, i + time_travel_step)
+            latent_travel = torch.cat([hist(travel_step), temp_x0], dim=1)
+            for j in range(i + 1, travel_step):
+                pt = velocity(latent_travel, j)
+                temp_x0_travel = latent_travel[:, -lfz:] + (sigmas[j + 1] - sigmas[j]) * pt[:, -lfz:]
+                if sde:
+                    psm = temp_x0_travel
+                    pos = latent_travel[:, -lfz:] + (0 - sigmas[j]) * pt[:, -lfz:]
+                    eta = 0.3
+                    delta_t = sigmas[j] - sigmas[j + 1]
+                    if delta_t < 0:
+                        delta_t = 0
+                    dsigma = sigmas[j + 1] - sigmas[j]
+                    std_dev_t = eta * math.sqrt(delta_t)
+                    score = -(latent_travel[:, -lfz:] - pos * (1 - sigmas[j])) / sigmas[j] ** 2
+                    psm = psm + (-0.5 * eta ** 2 * score) * dsigma
+                    temp_x0_travel = psm + randn(psm.shape) * std_dev_t
+                latent_travel = torch.cat([hist(min(S - 1, j + 1)), temp_x0_travel], dim=1)
+                current_pred = pt
+            temp_x0 = latent[:, -lfz:] + (nxt - sigmas[i]) * current_pred[:, -lfz:]
+        latent = torch.cat([hist(min(S - 1, i + 1)), temp_x0], dim=1)
+    return latent

@@ -1,0 +1,88 @@
+"""Multi-GPU sampling: one process per GPU, independent denoise chains, replicated weights.
+
+The reference's only multi-GPU mode at inference is data parallel over samples — `index = (step-1)*world_size + rank`
+(fastvideo/sample/sample_5b.py:782-785) — with the DiT wrapped in FSDP FULL_SHARD, i.e. a parameter all-gather per block
+per forward that exists only because of 80 GB GPUs. On MI355X (288 GB HBM3E) the weights are replicated, so there is NO
+collective inside the step loop; RCCL (torch.distributed backend "nccl" on ROCm; "gloo" in the CPU tests) is used for
+  * broadcast_module_: one-time weight broadcast from rank 0 in few, large flat buckets (xGMI rings are per-link bound,
+    so bucket size rather than message count is what matters);
+  * all_gather_results / gather_scalars: result latents, checksums and timings at chunk end.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend=None):
+    """Initialise the default process group from torchrun's env (RANK / WORLD_SIZE / LOCAL_RANK / MASTER_*)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        kw = {}
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+            kw["device_id"] = torch.device("cuda", local)
+        dist.init_process_group(backend, **kw)
+    return rank, world, local
+
+
+def shard_indices(n_items, rank, world):
+    """items processed by `rank`: index = (step-1)*world + rank for step = 1, 2, ... (sample_5b.py:782-785)."""
+    return list(range(rank, n_items, world))
+
+
+@torch.no_grad()
+def broadcast_module_(module, src=0, bucket_bytes=1 << 30):
+    """Replicate rank `src`'s parameters and buffers on every rank with flat-bucketed broadcasts."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return 0
+    tensors = [p.data for p in module.parameters()] + [b.data for b in module.buffers()]
+    n_coll = 0
+    by_dtype = {}
+    for t in tensors:
+        by_dtype.setdefault((t.dtype, t.device), []).append(t)
+    for (dtype, dev), ts in by_dtype.items():
+        cap = max(1, bucket_bytes // ts[0].element_size())
+        i = 0
+        while i < len(ts):
+            group, n = [], 0
+            while i < len(ts) and (not group or n + ts[i].numel() <= cap):
+                group.append(ts[i])
+                n += ts[i].numel()
+                i += 1
+            flat = torch.empty(n, dtype=dtype, device=dev)
+            off = 0
+            if dist.get_rank() == src:
+                for t in group:
+                    flat[off:off + t.numel()].copy_(t.reshape(-1))
+                    off += t.numel()
+            dist.broadcast(flat, src=src)
+            n_coll += 1
+            off = 0
+            for t in group:
+                t.copy_(flat[off:off + t.numel()].view_as(t))
+                off += t.numel()
+    return n_coll
+
+
+def all_gather_results(t):
+    """[world, *t.shape]: every rank's result tensor (e.g. the [48,8,44,80] latents of its chain)."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return t.unsqueeze(0)
+    out = [torch.empty_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t.contiguous())
+    return torch.stack(out)
+
+
+def gather_scalars(x, device=None):
+    """list of one python float per rank (timings, checksums)."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return [float(x)]
+    dev = device or (torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else "cpu")
+    t = torch.tensor([float(x)], dtype=torch.float64, device=dev)
+    return [float(v) for v in all_gather_results(t).flatten()]
