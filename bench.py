@@ -40,6 +40,50 @@ def flops_fwd_5b(L, C=3072, ffn=14336, n=30, Lc=512, cin=48, cout=48):
     return n * blk + 2 * L * (cin * 4) * C + 2 * 512 * (4096 * C + C * C) + 2 * L * (256 * C + C * C + 6 * C * C) + 2 * L * C * 4 * cout
 
 
+def pmc_traffic_bytes():
+    """HBM/fabric bytes per launch of the dominant kernel from the committed rocprofv3 PMC pass
+    (profiles/r1_pmc_dominant_kernels.csv: FETCH_SIZE and WRITE_SIZE in KiB; FETCH_SIZE doubled per the gfx950
+    calibration in MI355X_MICROARCH.md, confirmed on the adaLN kernel: 2*FETCH = 4*L*C exactly)."""
+    import csv
+    path = os.path.join(ROOT, "profiles", "r1_pmc_dominant_kernels.csv")
+    try:
+        for r in csv.DictReader(open(path)):
+            if "gemm256_kernel<1" in r["kernel"]:
+                return (2.0 * float(r["FETCH_SIZE"]) + float(r["WRITE_SIZE"])) * 1024.0
+    except Exception:  # noqa: BLE001
+        pass
+    return None
+
+
+def vae_decode_rate(dev, z8):
+    """Wan2.2 VAE decode of one chunk (8 latents [48,8,44,80] -> 29 frames 704x1280), random-init weights:
+    the second half of BASELINE.json's metric ("VAE dec latents/s"). Not part of `value`."""
+    from yume_amd import synth
+    from yume_amd.wan23.modules.vae2_2 import Wan2_2_VAE, WanVAE_
+    cfg = synth.VAE_CFG_22
+    with torch.device(dev):
+        m = WanVAE_(dim=cfg["dim"], dec_dim=cfg["dec_dim"], z_dim=cfg["z_dim"], temperal_downsample=cfg["temperal_downsample"])
+    g = torch.Generator(device=dev).manual_seed(5)
+    with torch.no_grad():
+        for k, p in m.named_parameters():
+            if k.endswith("gamma"):
+                p.copy_(1 + 0.1 * torch.randn(p.shape, generator=g, device=dev))
+            elif k.endswith("bias"):
+                p.copy_(0.02 * torch.randn(p.shape, generator=g, device=dev))
+            else:
+                p.copy_((torch.rand(p.shape, generator=g, device=dev) * 2 - 1) * (3.0 / p[0].numel()) ** 0.5)
+    vae = Wan2_2_VAE(device=dev, model=m)
+    vae.decode([z8])                                   # warm-up
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    out = vae.decode([z8])[0]
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    assert torch.isfinite(out).all()
+    return {"latents_per_s": z8.shape[1] / dt, "ms_per_chunk": dt * 1e3, "chunk": "8 latents 48x8x44x80 -> 29 frames 704x1280",
+            "tflop_per_chunk": 485.04, "tflops": 485.04 / dt}
+
+
 def cpu_baseline(cfg, L, n_hist, seconds_budget=30.0):
     """Reference restatement on the host cores: one full-width block at the full sequence length."""
     from oracle import dit as odit
@@ -74,6 +118,76 @@ def cpu_baseline(cfg, L, n_hist, seconds_budget=30.0):
             "sample": f"1 of {cfg['num_layers']} DiT blocks at L={L} (fp32, {dt:.2f} s), extrapolated x{cfg['num_layers']}; embed/head excluded"}
 
 
+def bench_14b(args, rank, world, dev):
+    """BASELINE configs[2]: Yume-I2V-14B-540P random-init, 65-frame 544x960 clip (latent [16,17,68,120] + y[20,...]),
+    FramePack (rand_num_img=0.6, latent_frame_zero=9), CFG 5.0 -> two forwards per step, history re-noised each step
+    (fastvideo/sample/sample.py:745-790). L = 27810 tokens, 2 x 1319.3 TFLOP per step."""
+    from yume_amd import distributed as ydist
+    from yume_amd import framepack, sampling, synth
+    from yume_amd.wan.modules.model import WanModel
+    cfg = dict(synth.CFG_14B)
+    if args.layers:
+        cfg["num_layers"] = args.layers
+    F, H, W, lfz, S, shift = 17, 68, 120, 9, 50, 3.0
+    with torch.device(dev):
+        model = WanModel(**cfg).attach_pyramid()
+    if rank == 0:
+        synth.randomize_module_(model, seed=0)
+    model = model.to(torch.bfloat16).eval().requires_grad_(False)
+    ydist.broadcast_module_(model, src=0)
+    L = framepack.pack_plan(F, H, W, lfz, F - 9).seq_len
+    g = torch.Generator(device=dev).manual_seed(2000 + rank)
+    clean = torch.randn((16, F, H, W), generator=g, device=dev)
+    noise = torch.randn((16, F, H, W), generator=g, device=dev)
+    y = [torch.randn((20, F, H, W), generator=g, device=dev)]
+    clip = torch.randn((1, 257, 1280), generator=g, device=dev)
+    arg_c = dict(context=[torch.randn((77, 4096), generator=g, device=dev)], clip_fea=clip, seq_len=L, y=y)
+    arg_null = dict(context=[torch.randn((77, 4096), generator=g, device=dev)], clip_fea=clip, seq_len=L, y=y)
+    sig = synth.sampling_sigmas(S, shift)
+    vel = sampling.make_velocity_14b(model, arg_c, arg_null, sig, guide=5.0, rand_num_img=0.6, lfz=lfz)
+    hist = sampling.renoised_history(clean[:, :-lfz], noise[:, :-lfz], sig)
+    latent = noise.clone()
+
+    def step(i, latent):
+        k = i % S
+        v = vel(latent, k)
+        nxt = sig[k + 1] if k + 1 < S else 0.0
+        x = latent[:, -lfz:] + (nxt - sig[k]) * v[:, -lfz:]
+        return torch.cat([hist(min(S - 1, k + 1)), x], dim=1)
+
+    for i in range(args.warmup):
+        latent = step(i, latent)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.warmup, args.warmup + args.steps):
+        latent = step(i, latent)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    assert torch.isfinite(latent).all()
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    tmax = float(tmax.item())
+    if rank == 0:
+        ms = tmax / args.steps * 1e3
+        tf = 2 * 1319.3 * (cfg["num_layers"] / 40.0)
+        print(json.dumps({"metric": "denoise-steps/sec (Yume-I2V-14B 540P, 65-frame latent, CFG)", "value": world * args.steps / tmax,
+                          "unit": "denoise-steps/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+                          "config": {"workload": "Yume-I2V-14B-540P random-init, latent 16x17x68x120 + y, FramePack lfz=9, L=27810, CFG 5.0 "
+                                                 "(2 forwards/step), 50-step shift-3 schedule", "num_layers": cfg["num_layers"], "tokens": L},
+                          "model_tflop_per_step": tf, "model_tflops_per_gpu": tf / (ms * 1e-3),
+                          "peak_mem_gb": torch.cuda.max_memory_allocated() / 1e9}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -81,6 +195,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--layers", type=int, default=0, help="debug only: override num_layers (result is then NOT the named config)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-vae", action="store_true", help="skip the (untimed-in-value) VAE decode measurement")
+    ap.add_argument("--workload", default="5b", choices=["5b", "14b"],
+                    help="5b = BASELINE configs[1] (the headline metric, default); 14b = configs[2] (Yume-I2V-14B-540P, 65-frame clip, CFG)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -100,14 +217,19 @@ def main():
     from yume_amd import framepack, synth
     from yume_amd.wan23.modules.model import WanModel
 
+    if args.workload == "14b":
+        return bench_14b(args, rank, world, dev)
     cfg = dict(synth.CFG_5B)
     if args.layers:
         cfg["num_layers"] = args.layers
     F, H, W, lfz, steps_total, shift = 13, 44, 80, 8, 50, 7.0
+    from yume_amd import distributed as ydist
     with torch.device(dev):
         model = WanModel(**cfg)
-    synth.randomize_module_(model, seed=0)           # replicated weights: same seed on every rank
+    if rank == 0:
+        synth.randomize_module_(model, seed=0)
     model = model.to(torch.bfloat16).eval().requires_grad_(False)   # sample_5b.py:1241 casts the transformer to bf16
+    n_bcast = ydist.broadcast_module_(model, src=0)   # replicated weights: one-time RCCL broadcast, flat 1 GiB buckets
     plan = framepack.pack_plan(F, H, W, lfz)
     L = plan.seq_len
 
@@ -144,6 +266,12 @@ def main():
     dt = time.perf_counter() - t0
     prof, model.engine.prof = model.engine.prof, None
     assert torch.isfinite(latent).all(), "non-finite latents"
+    # results of every chain are gathered at chunk end (the only other collective of the run)
+    checks = ydist.gather_scalars(float(latent[:, -lfz:].double().abs().mean()), device=dev)
+
+    vae_res = None
+    if not args.no_vae and rank == 0:
+        vae_res = vae_decode_rate(dev, latent[:, -lfz:].float())
 
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
@@ -163,11 +291,13 @@ def main():
             "config": {"workload": "Yume-5B-720P random-init, 33-frame 704x1280 clip (latent 48x13x44x80, FramePack "
                                    "lfz=8, L=9460), ODE Euler steps of a 50-step shift-7 schedule, no CFG, one chain per GPU",
                        "num_layers": cfg["num_layers"], "tokens": L, "parallelism": f"dp{world} (independent chains, replicated weights)"},
+            "chain_checksums": checks, "weight_broadcast_collectives": n_bcast,
+            "vae_decode": vae_res,
             "model_tflop_per_step": flops_fwd_5b(L, n=cfg["num_layers"]) / 1e12,
             "model_tflops_per_gpu": flops_fwd_5b(L, n=cfg["num_layers"]) / 1e12 / (ms_per_step * 1e-3),
-            "roofline": {"bound": "mfma", "kernel": "gemm128_kernel<EPI_BF16_GELU> ffn.0 9460x14336x3072",
+            "roofline": {"bound": "mfma", "kernel": "gemm256_kernel<EPI_BF16_GELU, PlainA> ffn.0 9460x14336x3072",
                          "achieved": achieved, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / MFMA_BF16_PEAK_TFLOPS, "traffic": None,
+                         "frac": achieved / MFMA_BF16_PEAK_TFLOPS, "traffic": pmc_traffic_bytes(),
                          "launch_ms": gemm_ms, "launches_timed": len(prof)},
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -331,7 +331,7 @@ __device__ __forceinline__ void stage_store_v2(const Stage& s, char* buf, int ti
     }
 }
 
-template <bool MASK, int PIPE>
+template <bool MASK>
 __device__ __forceinline__ void tile_body_v2(const char* kb, const AttnArgs& p, const bf16x8_t (&qf)[8],
                                              f32x16 (&oacc)[4], float& m_run, float& l_run, int j0, int ql, int hi) {
     const char* vb = kb + K_TILE_BYTES;
@@ -398,45 +398,20 @@ __device__ __forceinline__ void tile_body_v2(const char* kb, const AttnArgs& p, 
             pf[2 * b + e] = __builtin_bit_cast(bf16x8_t, w);
         }
 
-    // ---- O^T += V^T . P^T ----
-    if (PIPE == 0) {
+    // ---- O^T += V^T . P^T ---- (an explicit one-d-block-ahead fragment prefetch was measured: no gain, dropped)
 #pragma unroll
-        for (int db = 0; db < 4; ++db) {
-            const int d = 32 * db + ql;
-            const char* vrow = vb + d * 128;
-            const int sw = (d >> 1) & 7;
+    for (int db = 0; db < 4; ++db) {
+        const int d = 32 * db + ql;
+        const char* vrow = vb + d * 128;
+        const int sw = (d >> 1) & 7;
 #pragma unroll
-            for (int sg = 0; sg < 4; ++sg) {
-                const bf16x8_t vf = *reinterpret_cast<const bf16x8_t*>(vrow + (((2 * sg + hi) ^ sw) << 4));
-                oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[sg], oacc[db], 0, 0, 0);
-            }
-        }
-    } else {
-        // explicit one-d-block-ahead fragment prefetch: the 4 reads of d-block db+1 are issued before the MFMAs of db
-        bf16x8_t vf[2][4];
-        {
-            const int sw = (ql >> 1) & 7;
-#pragma unroll
-            for (int sg = 0; sg < 4; ++sg) vf[0][sg] = *reinterpret_cast<const bf16x8_t*>(vb + ql * 128 + (((2 * sg + hi) ^ sw) << 4));
-        }
-#pragma unroll
-        for (int db = 0; db < 4; ++db) {
-            if (db < 3) {
-                const int d = 32 * (db + 1) + ql;
-                const int sw = (d >> 1) & 7;
-#pragma unroll
-                for (int sg = 0; sg < 4; ++sg)
-                    vf[(db + 1) & 1][sg] = *reinterpret_cast<const bf16x8_t*>(vb + d * 128 + (((2 * sg + hi) ^ sw) << 4));
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int sg = 0; sg < 4; ++sg)
-                oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[db & 1][sg], pf[sg], oacc[db], 0, 0, 0);
+        for (int sg = 0; sg < 4; ++sg) {
+            const bf16x8_t vf = *reinterpret_cast<const bf16x8_t*>(vrow + (((2 * sg + hi) ^ sw) << 4));
+            oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[sg], oacc[db], 0, 0, 0);
         }
     }
 }
 
-template <int PIPE>
 __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel_v2(AttnArgs p) {
     __shared__ __attribute__((aligned(16))) char smem[2 * V2_BUF];
     const int tid = threadIdx.x;
@@ -490,9 +465,9 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel_v2(AttnArgs p) {
         const bool next_reg = has_next && ragged && (t + 2 == nt);
         if (has_next && !next_reg) dma_tile(p, h, (t + 1) * KT, nb, tid, wave);
         if (!has_next && ragged)
-            tile_body_v2<true, PIPE>(kb, p, qf, oacc, m_run, l_run, t * KT, ql, hi);
+            tile_body_v2<true>(kb, p, qf, oacc, m_run, l_run, t * KT, ql, hi);
         else
-            tile_body_v2<false, PIPE>(kb, p, qf, oacc, m_run, l_run, t * KT, ql, hi);
+            tile_body_v2<false>(kb, p, qf, oacc, m_run, l_run, t * KT, ql, hi);
         if (next_reg) {
             Stage st;
             stage_load(st, p, h, (t + 1) * KT, tid);
@@ -556,10 +531,8 @@ extern "C" int yume_attn_fwd(const void* Q, int64_t ldq, const void* K, int64_t 
     dim3 grid((unsigned)(per_xcd * 8)), block(NW * 64);
     if (variant == 1)
         hipLaunchKernelGGL(attn_fwd_kernel, grid, block, 0, (hipStream_t)stream, a);
-    else if (variant == 3)
-        hipLaunchKernelGGL(attn_fwd_kernel_v2<1>, grid, block, 0, (hipStream_t)stream, a);
     else
-        hipLaunchKernelGGL(attn_fwd_kernel_v2<0>, grid, block, 0, (hipStream_t)stream, a);
+        hipLaunchKernelGGL(attn_fwd_kernel_v2, grid, block, 0, (hipStream_t)stream, a);
     YUME_CHECK_LAUNCH("attn_fwd");
     return YUME_OK;
 }
