@@ -110,3 +110,60 @@ def test_missing_extension_is_loud(monkeypatch):
     monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libyume_hip.so")
     with pytest.raises(RuntimeError, match="no CPU/PyTorch fallback"):
         _lib.load()
+
+
+@pytest.mark.parametrize("family,F,lfz", [("wan23", 40, 8), ("wan23", 110, 8), ("wan23", 360, 8), ("wan", 100, 9), ("wan", 12, 8)])
+def test_deep_framepack_levels_vs_oracle(family, F, lfz):
+    """history long enough for the 8x / 16x / (2x_f -> 16x) pyramid levels (model.py:640-718); the oracle is pinned to the
+    reference for the same shapes in tests/test_oracle_dit.py."""
+    from yume_amd import framepack
+    cfg = synth.tiny_cfg(family, layers=1)
+    sd = synth.make_dit_state_dict(cfg, family, seed=21)
+    inp = synth.make_dit_inputs(cfg, family, F, 10, 12, n_text=9, seed=22)
+    plan = framepack.pack_plan(F, 10, 12, lfz, (F - 9) if family == "wan" else None)
+    L = plan.seq_len
+    if family == "wan23":
+        t = torch.cat([torch.zeros(plan.n_hist_tok), torch.full((plan.n_new_tok,), 333.25)]).unsqueeze(0).double()
+        want = odit.forward_wan23(sd, cfg, inp["x"], t, inp["context"], L, lfz, True)
+    else:
+        t = torch.tensor([250.0])
+        want = odit.forward_wan(sd, cfg, inp["x"], t, inp["context"], L, inp["clip_fea"][0], inp["y"], 0.6, lfz)
+    m = build_model(family, cfg, sd)
+    got = run_model(m, family, dict(inputs=inp, t=t, seq_len=L, lfz=lfz, packed=True))
+    assert got.shape == want.shape
+    e = rel_l2(got, want)
+    print(f"{family} F={F}: L={L} rel-L2 {e:.3e}")
+    assert e <= 1.5e-2
+
+
+def test_per_token_timesteps_on_the_plain_path():
+    """wan23 plain path with an arbitrary per-token t [1, seq_len] (textimage2video's i2v masks the first frame to t=0)."""
+    cfg = synth.tiny_cfg("wan23", layers=1)
+    sd = synth.make_dit_state_dict(cfg, "wan23", seed=5)
+    inp = synth.make_dit_inputs(cfg, "wan23", 3, 8, 12, n_text=7, seed=6)
+    L = 3 * 4 * 6
+    t = torch.full((1, L), 700.0)
+    t[0, :24] = 0.0
+    t[0, 30:40] = 123.5
+    want = odit.forward_wan23(sd, cfg, inp["x"], t, inp["context"], L, 8, False)
+    m = build_model("wan23", cfg, sd)
+    got = m([inp["x"].to(DEV)], t=t.to(DEV), context=[inp["context"].to(DEV)], seq_len=L, flag=False)[0].cpu()
+    assert rel_l2(got, want) <= 1.5e-2
+
+
+def test_long_video_loop_with_vae():
+    """two chunks of the FramePack loop + VAE decode per chunk on tiny models: shapes, finiteness, history growth."""
+    from yume_amd import sampling
+    from yume_amd.wan23.modules.vae2_2 import Wan2_2_VAE, WanVAE_
+    cfg = synth.tiny_cfg("wan23", layers=1)
+    m = build_model("wan23", cfg, synth.make_dit_state_dict(cfg, "wan23", seed=1))
+    vcfg = synth.tiny_vae_cfg("2.2")
+    vm = WanVAE_(dim=vcfg["dim"], dec_dim=vcfg["dec_dim"], z_dim=48, temperal_downsample=vcfg["temperal_downsample"])
+    vm.load_state_dict(synth.make_vae_state_dict(vcfg, 2))
+    vae = Wan2_2_VAE(device=DEV, model=vm)
+    g = torch.Generator(device=DEV).manual_seed(0)
+    hist = torch.randn(48, 5, 4, 6, device=DEV, generator=g)
+    ctxs = [torch.randn(9, cfg["text_dim"], device=DEV, generator=g) for _ in range(2)]
+    lat, vids = sampling.long_video_5b(m, vae, hist, ctxs, steps=2, generator=g)
+    assert lat.shape == (48, 5 + 16, 4, 6) and torch.isfinite(lat).all()
+    assert len(vids) == 2 and vids[0].shape == (3, 29, 64, 96) and all(torch.isfinite(v).all() for v in vids)

@@ -51,7 +51,9 @@ def test_sigmas_match_reference_formula():
 
 @pytest.mark.skipif(not ref_import.available(), reason="reference tree not present (GPU box)")
 @pytest.mark.parametrize("family,F,lfz,packed", [("wan23", 15, 8, True), ("wan23", 32, 8, True), ("wan23", 3, 8, False),
-                                                 ("wan", 16, 9, True), ("wan", 12, 8, True), ("wan", 3, 9, False)])
+                                                 ("wan", 16, 9, True), ("wan", 12, 8, True), ("wan", 3, 9, False),
+                                                 ("wan23", 40, 8, True), ("wan23", 110, 8, True), ("wan23", 360, 8, True),
+                                                 ("wan", 100, 9, True)])
 def test_oracle_matches_live_reference(family, F, lfz, packed):
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     from make_golden import build_reference, run_reference, token_count

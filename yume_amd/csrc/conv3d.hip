@@ -110,6 +110,7 @@ extern "C" int yume_conv3d_cl(const void* x, const void* cache, int64_t ldc, int
     p.M = (int)M; p.N = (int)Cout; p.K = (int)Kp;
     p.tiles_m = (int)((M + BM - 1) / BM);
     p.tiles_n = (int)((Cout + BN - 1) / BN);
+    p.group_m = 8;
     ConvA al = {};
     al.x = (const unsigned short*)x; al.cache = (const unsigned short*)cache; al.zero = (const unsigned short*)zero_page;
     al.ldc = ldc;

@@ -21,6 +21,7 @@ extern "C" int yume_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t
     p.M = (int)M; p.N = (int)N; p.K = (int)K;
     p.tiles_m = (int)((M + BM - 1) / BM);
     p.tiles_n = (int)((N + BN - 1) / BN);
+    p.group_m = 8;
     PlainA al;
     al.A = (const unsigned short*)A; al.lda = lda; al.M = (int)M;
     Epilogue e = {};

@@ -42,6 +42,7 @@ struct Problem {
     const unsigned short* W; int64_t ldw;
     int M, N, K;
     int tiles_m, tiles_n;
+    int group_m;   // 256^2 kernel: M-tiles per traversal group (L2 reuse knob)
 };
 
 typedef __attribute__((address_space(3))) void lds_void;
@@ -324,30 +325,15 @@ __device__ __forceinline__ void stage_half_b(const unsigned short* const (&wrow)
 #define YUME_PHASE_END() \
     if (PRIO) __builtin_amdgcn_s_setprio(0)
 
-template <int EPI, class ALoad, bool PRIO = true>
-__global__ __launch_bounds__(NTHR256, 2) void gemm256_kernel(Problem p, ALoad al, Epilogue e) {
-    __shared__ __attribute__((aligned(16))) char smem[LDS256_BYTES];
+// SWAP = true computes the transposed product (B fragment as the MFMA's first operand) so that a lane ends up with
+// 4 CONSECUTIVE COLUMNS n of one row m: the row-major epilogues then store 8/16-byte vectors straight from the
+// accumulators (no LDS restage). SWAP = false leaves 4 consecutive rows m per column n: the K-major V^T store.
+template <int EPI, class ALoad, bool PRIO, bool SWAP>
+__device__ __forceinline__ void gemm256_body(const Problem& p, ALoad& al, const Epilogue& e, char* smem, int m0, int n0) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 2, wc = wave & 3;
-
-    // ---- workgroup -> tile (XCD-aware, grouped) ----
-    const int nwg = p.tiles_m * p.tiles_n;
-    int wg;
-    {
-        const int bid = blockIdx.x;
-        const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
-        wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-    }
-    constexpr int GROUP_M = 4;
-    const int width = GROUP_M * p.tiles_n;
-    const int group = wg / width;
-    const int first_m = group * GROUP_M;
-    const int gsz = min(p.tiles_m - first_m, GROUP_M);
-    const int tm = first_m + (wg % width) % gsz;
-    const int tn = (wg % width) / gsz;
-    const int m0 = tm * 256, n0 = tn * 256;
 
     // W rows of this thread: half-tile nh, round r2 -> row nh*128 + r2*64 + tid/8 (clamped), source chunk swizzled
     const unsigned short* wrow[4];
@@ -420,7 +406,8 @@ __global__ __launch_bounds__(NTHR256, 2) void gemm256_kernel(Problem p, ALoad al
             for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
                 for (int ni = 0; ni < 2; ++ni)
-                    acc[0][0][mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mi][ks], b[ni][ks], acc[0][0][mi][ni], 0, 0, 0);
+                    acc[0][0][mi][ni] = SWAP ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[ni][ks], a[mi][ks], acc[0][0][mi][ni], 0, 0, 0)
+                                             : __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mi][ks], b[ni][ks], acc[0][0][mi][ni], 0, 0, 0);
         YUME_PHASE_END();
 
         // ---------------- P2: quadrant (0,1) ----------------
@@ -436,7 +423,8 @@ __global__ __launch_bounds__(NTHR256, 2) void gemm256_kernel(Problem p, ALoad al
             for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
                 for (int ni = 0; ni < 2; ++ni)
-                    acc[0][1][mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mi][ks], b[ni][ks], acc[0][1][mi][ni], 0, 0, 0);
+                    acc[0][1][mi][ni] = SWAP ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[ni][ks], a[mi][ks], acc[0][1][mi][ni], 0, 0, 0)
+                                             : __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mi][ks], b[ni][ks], acc[0][1][mi][ni], 0, 0, 0);
         YUME_PHASE_END();
 
         // ---------------- P3: quadrant (1,1) ----------------
@@ -452,7 +440,8 @@ __global__ __launch_bounds__(NTHR256, 2) void gemm256_kernel(Problem p, ALoad al
             for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
                 for (int ni = 0; ni < 2; ++ni)
-                    acc[1][1][mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mi][ks], b[ni][ks], acc[1][1][mi][ni], 0, 0, 0);
+                    acc[1][1][mi][ni] = SWAP ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[ni][ks], a[mi][ks], acc[1][1][mi][ni], 0, 0, 0)
+                                             : __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mi][ks], b[ni][ks], acc[1][1][mi][ni], 0, 0, 0);
         YUME_PHASE_END();
 
         // ---------------- P4: quadrant (1,0) ----------------
@@ -474,40 +463,134 @@ __global__ __launch_bounds__(NTHR256, 2) void gemm256_kernel(Problem p, ALoad al
             for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
                 for (int ni = 0; ni < 2; ++ni)
-                    acc[1][0][mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mi][ks], b[ni][ks], acc[1][0][mi][ni], 0, 0, 0);
+                    acc[1][0][mi][ni] = SWAP ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[ni][ks], a[mi][ks], acc[1][0][mi][ni], 0, 0, 0)
+                                             : __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mi][ks], b[ni][ks], acc[1][0][mi][ni], 0, 0, 0);
         YUME_PHASE_END();
     }
 
-    // ---- epilogue: every LDS read finished before the last barrier; each wave restages its two 64x64 halves
-    //      through its private 16 KiB and stores them with the fused epilogue ----
-    float* ep = reinterpret_cast<float*>(smem) + wave * (64 * 64);
-    const bool transposed = (EPI == YUME_EPI_BF16_SPLITT) && (n0 >= e.n_split);
+    // ---- epilogue: vector stores straight from the accumulators ----
+    const int l15 = lane & 15, l4 = lane >> 4;
 #pragma unroll
-    for (int mh = 0; mh < 2; ++mh) {
+    for (int mh = 0; mh < 2; ++mh)
 #pragma unroll
         for (int nh = 0; nh < 2; ++nh)
 #pragma unroll
             for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-                for (int ni = 0; ni < 2; ++ni) stage_acc(ep, acc[mh][nh][mi][ni], mi, nh * 2 + ni, lane, transposed);
-        wave_epilogue<EPI>(ep, transposed, p, e, lane, m0 + mh * 128 + wr * 64, n0 + wc * 32, n0 + 128 + wc * 32);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // staging reads done before the next half overwrites it
-        __builtin_amdgcn_wave_barrier();
+                for (int ni = 0; ni < 2; ++ni) {
+                    const int mb = m0 + mh * 128 + wr * 64 + mi * 16;
+                    const int nb = n0 + nh * 128 + wc * 32 + ni * 16;
+                    f32x4 v = acc[mh][nh][mi][ni];
+                    if (SWAP) {
+                        const int m = mb + l15, n = nb + 4 * l4;        // v = C[m][n .. n+3]
+                        if (m >= p.M || n >= p.N) continue;
+                        if (e.bias) v += *reinterpret_cast<const f32x4*>(e.bias + n);
+                        if (EPI == YUME_EPI_F32) {
+                            *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(e.out) + (int64_t)m * e.ldo + n) = v;
+                        } else if (EPI == YUME_EPI_RESID) {
+                            float* xo = reinterpret_cast<float*>(e.out) + (int64_t)m * e.ldo + n;
+                            f32x4 x = *reinterpret_cast<const f32x4*>(xo);
+                            if (e.gate) {
+                                const int64_t row = e.row_idx ? (int64_t)e.row_idx[m] : 0;
+                                x += v * *reinterpret_cast<const f32x4*>(e.gate + row * e.gate_stride + n);
+                            } else {
+                                x += v;
+                            }
+                            *reinterpret_cast<f32x4*>(xo) = x;
+                        } else {
+                            if (EPI == YUME_EPI_BF16_GELU) {
+#pragma unroll
+                                for (int q = 0; q < 4; ++q) v[q] = gelu_tanh(v[q]);
+                            }
+                            if (EPI == YUME_EPI_BF16_GELU_ERF) {
+#pragma unroll
+                                for (int q = 0; q < 4; ++q) v[q] = 0.5f * v[q] * (1.0f + erff(v[q] * 0.7071067811865476f));
+                            }
+                            if (EPI == EPI_BF16_ADD) {
+                                const u32x2 a2 = *reinterpret_cast<const u32x2*>(e.add + (int64_t)m * e.ldadd + n);
+                                v[0] += bf16_to_f32((unsigned short)(a2[0] & 0xffffu));
+                                v[1] += bf16_to_f32((unsigned short)(a2[0] >> 16));
+                                v[2] += bf16_to_f32((unsigned short)(a2[1] & 0xffffu));
+                                v[3] += bf16_to_f32((unsigned short)(a2[1] >> 16));
+                            }
+                            int64_t orow = m;
+                            int ocol = n;
+                            if (EPI == EPI_BF16_TSPLIT) {
+                                const int ch = p.N >> 1;
+                                const int j = n >= ch ? 1 : 0;
+                                const int t = m / e.hw;
+                                orow = (int64_t)m + (int64_t)(t + j) * e.hw;
+                                ocol = n - j * ch;
+                            }
+                            u32x2 o;
+                            o[0] = pack_bf16x2(v[0], v[1]);
+                            o[1] = pack_bf16x2(v[2], v[3]);
+                            *reinterpret_cast<u32x2*>(reinterpret_cast<unsigned short*>(e.out) + orow * e.ldo + ocol) = o;
+                        }
+                    } else {
+                        const int m = mb + 4 * l4, n = nb + l15;        // v = C[m .. m+3][n]  -> outT[n - n_split][m .. m+3]
+                        if (m >= p.M || n >= p.N) continue;
+                        const float bn = e.bias ? e.bias[n] : 0.f;
+                        unsigned short* dst = e.outT + (int64_t)(n - e.n_split) * e.ldt + m;
+                        if (m + 3 < p.M) {
+                            u32x2 o;
+                            o[0] = pack_bf16x2(v[0] + bn, v[1] + bn);
+                            o[1] = pack_bf16x2(v[2] + bn, v[3] + bn);
+                            *reinterpret_cast<u32x2*>(dst) = o;
+                        } else {
+                            for (int q = 0; q < 4 && m + q < p.M; ++q) dst[q] = f32_to_bf16(v[q] + bn);
+                        }
+                    }
+                }
+}
+
+template <int EPI, class ALoad, bool PRIO = true>
+__global__ __launch_bounds__(NTHR256, 2) void gemm256_kernel(Problem p, ALoad al, Epilogue e) {
+    __shared__ __attribute__((aligned(16))) char smem[LDS256_BYTES];
+    // ---- workgroup -> tile (XCD-aware, grouped) ----
+    const int nwg = p.tiles_m * p.tiles_n;
+    int wg;
+    {
+        const int bid = blockIdx.x;
+        const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+        wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int width = p.group_m * p.tiles_n;
+    const int group = wg / width;
+    const int first_m = group * p.group_m;
+    const int gsz = min(p.tiles_m - first_m, p.group_m);
+    const int tm = first_m + (wg % width) % gsz;
+    const int tn = (wg % width) / gsz;
+    const int m0 = tm * 256, n0 = tn * 256;
+    if (EPI == YUME_EPI_BF16_SPLITT) {
+        if (n0 >= e.n_split)
+            gemm256_body<EPI, ALoad, PRIO, false>(p, al, e, smem, m0, n0);
+        else
+            gemm256_body<EPI, ALoad, PRIO, true>(p, al, e, smem, m0, n0);
+    } else {
+        gemm256_body<EPI, ALoad, PRIO, true>(p, al, e, smem, m0, n0);
     }
 }
 
 // A/B switch for the s_setprio(1) bracket around each phase's MFMA cluster (env YUME_GEMM_PRIO=0 disables)
 inline bool read_prio_env() {
     const char* v = getenv("YUME_GEMM_PRIO");
-    return !(v && v[0] == '0');
+    return v && v[0] == '1';
 }
 static const bool g_prio256 = read_prio_env();
+inline int read_group_env() {
+    const char* v = getenv("YUME_GEMM_GROUPM");
+    const int g = v ? atoi(v) : 4;
+    return g > 0 ? g : 4;
+}
+static const int g_group_m = read_group_env();
 
 template <int EPI, class ALoad>
 int launch256(const Problem& p128, const ALoad& al, const Epilogue& e, hipStream_t st, const char* what) {
     Problem p = p128;
     p.tiles_m = (p.M + 255) / 256;
     p.tiles_n = (p.N + 255) / 256;
+    p.group_m = g_group_m;
     dim3 grid((unsigned)(p.tiles_m * p.tiles_n)), block(NTHR256);
     if (g_prio256)
         hipLaunchKernelGGL((gemm256_kernel<EPI, ALoad, true>), grid, block, 0, st, p, al, e);
