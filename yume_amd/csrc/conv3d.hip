@@ -125,14 +125,14 @@ extern "C" int yume_conv3d_cl(const void* x, const void* cache, int64_t ldc, int
     hipStream_t s = (hipStream_t)stream;
     const bool big = use_256(p, variant, true);
     switch (epi) {
-        case YUME_EPI_BF16: return big ? launch256<YUME_EPI_BF16>(p, al, e, s, "conv3d_cl") : launch<YUME_EPI_BF16>(p, al, e, s, "conv3d_cl");
-        case YUME_EPI_F32: return big ? launch256<YUME_EPI_F32>(p, al, e, s, "conv3d_cl") : launch<YUME_EPI_F32>(p, al, e, s, "conv3d_cl");
+        case YUME_EPI_BF16: return big ? launch256<YUME_EPI_BF16>(p, al, e, s, "conv3d_cl", 0) : launch<YUME_EPI_BF16>(p, al, e, s, "conv3d_cl");
+        case YUME_EPI_F32: return big ? launch256<YUME_EPI_F32>(p, al, e, s, "conv3d_cl", 0) : launch<YUME_EPI_F32>(p, al, e, s, "conv3d_cl");
         case YUME_CONV_EPI_ADD:
             YUME_REQUIRE(add != nullptr && (ldadd % 4) == 0, "conv3d_cl: ADD epilogue needs an addend with ldadd %% 4 == 0");
-            return big ? launch256<EPI_BF16_ADD>(p, al, e, s, "conv3d_cl") : launch<EPI_BF16_ADD>(p, al, e, s, "conv3d_cl");
+            return big ? launch256<EPI_BF16_ADD>(p, al, e, s, "conv3d_cl", 0) : launch<EPI_BF16_ADD>(p, al, e, s, "conv3d_cl");
         case YUME_CONV_EPI_TSPLIT:
             YUME_REQUIRE((Cout % 8) == 0, "conv3d_cl: TSPLIT needs an even channel split");
-            return big ? launch256<EPI_BF16_TSPLIT>(p, al, e, s, "conv3d_cl") : launch<EPI_BF16_TSPLIT>(p, al, e, s, "conv3d_cl");
+            return big ? launch256<EPI_BF16_TSPLIT>(p, al, e, s, "conv3d_cl", 0) : launch<EPI_BF16_TSPLIT>(p, al, e, s, "conv3d_cl");
         default:
             yume_set_error("conv3d_cl: unknown epilogue %d", epi);
             return YUME_EINVAL;

@@ -321,14 +321,24 @@ __device__ __forceinline__ void stage_half_b(const unsigned short* const (&wrow)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      \
     __builtin_amdgcn_s_barrier();                           \
     __builtin_amdgcn_sched_barrier(0);                      \
-    if (PRIO) __builtin_amdgcn_s_setprio(1)
-#define YUME_PHASE_END() \
-    if (PRIO) __builtin_amdgcn_s_setprio(0)
+    if (MODE == 1 || MODE == 2) __builtin_amdgcn_s_setprio(1)
+#define YUME_PHASE_END()                                         \
+    if (MODE == 1 || MODE == 2) __builtin_amdgcn_s_setprio(0);   \
+    if (MODE >= 2) {                                             \
+        asm volatile("" ::: "memory");                           \
+        __builtin_amdgcn_s_barrier();                            \
+        __builtin_amdgcn_sched_barrier(0);                       \
+    }
 
+// MODE: 0 = one barrier per phase; 1 = + s_setprio(1) around the MFMA clusters; 2 = STAGGERED: a second barrier after every
+// MFMA cluster and the wr = 1 half of the waves running one barrier behind the wr = 0 half, so that of the two waves
+// sharing a SIMD (w and w+4) one is in its MFMA cluster while the other issues its ds_reads / LDS-DMA (+ setprio);
+// 3 = staggered without setprio. WAR/RAW still hold: a half-tile is re-staged one full phase after its last reader's
+// phase, and the counted vmcnt wait of every wave precedes the barrier that opens the first read of the next K tile.
 // SWAP = true computes the transposed product (B fragment as the MFMA's first operand) so that a lane ends up with
 // 4 CONSECUTIVE COLUMNS n of one row m: the row-major epilogues then store 8/16-byte vectors straight from the
 // accumulators (no LDS restage). SWAP = false leaves 4 consecutive rows m per column n: the K-major V^T store.
-template <int EPI, class ALoad, bool PRIO, bool SWAP>
+template <int EPI, class ALoad, int MODE, bool SWAP>
 __device__ __forceinline__ void gemm256_body(const Problem& p, ALoad& al, const Epilogue& e, char* smem, int m0, int n0) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -379,6 +389,10 @@ __device__ __forceinline__ void gemm256_body(const Problem& p, ALoad& al, const 
     }
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
+    if (MODE >= 2 && wr == 1) {               // the wr = 1 waves run one barrier behind
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    }
 
     const int arow = wr * 64 + (lane & 15);   // + mi*16 : row inside half-tile A_mh
     const int brow = wc * 32 + (lane & 15);   // + ni*16 : row inside half-tile B_nh
@@ -468,6 +482,7 @@ __device__ __forceinline__ void gemm256_body(const Problem& p, ALoad& al, const 
         YUME_PHASE_END();
     }
 
+    if (MODE >= 2 && wr == 0) __builtin_amdgcn_s_barrier();   // barrier counts of the two halves match again
     // ---- epilogue: vector stores straight from the accumulators ----
     const int l15 = lane & 15, l4 = lane >> 4;
 #pragma unroll
@@ -544,7 +559,7 @@ __device__ __forceinline__ void gemm256_body(const Problem& p, ALoad& al, const 
                 }
 }
 
-template <int EPI, class ALoad, bool PRIO = true>
+template <int EPI, class ALoad, int MODE>
 __global__ __launch_bounds__(NTHR256, 2) void gemm256_kernel(Problem p, ALoad al, Epilogue e) {
     __shared__ __attribute__((aligned(16))) char smem[LDS256_BYTES];
     // ---- workgroup -> tile (XCD-aware, grouped) ----
@@ -564,20 +579,21 @@ __global__ __launch_bounds__(NTHR256, 2) void gemm256_kernel(Problem p, ALoad al
     const int m0 = tm * 256, n0 = tn * 256;
     if (EPI == YUME_EPI_BF16_SPLITT) {
         if (n0 >= e.n_split)
-            gemm256_body<EPI, ALoad, PRIO, false>(p, al, e, smem, m0, n0);
+            gemm256_body<EPI, ALoad, MODE, false>(p, al, e, smem, m0, n0);
         else
-            gemm256_body<EPI, ALoad, PRIO, true>(p, al, e, smem, m0, n0);
+            gemm256_body<EPI, ALoad, MODE, true>(p, al, e, smem, m0, n0);
     } else {
-        gemm256_body<EPI, ALoad, PRIO, true>(p, al, e, smem, m0, n0);
+        gemm256_body<EPI, ALoad, MODE, true>(p, al, e, smem, m0, n0);
     }
 }
 
-// A/B switch for the s_setprio(1) bracket around each phase's MFMA cluster (env YUME_GEMM_PRIO=0 disables)
-inline bool read_prio_env() {
-    const char* v = getenv("YUME_GEMM_PRIO");
-    return v && v[0] == '1';
+// schedule variant of the 256^2 kernel (see MODE above); env YUME_GEMM_MODE overrides for A/B runs
+inline int read_mode_env() {
+    const char* v = getenv("YUME_GEMM_MODE");
+    const int m = v ? atoi(v) : -1;
+    return (m >= 0 && m <= 3) ? m : -1;
 }
-static const bool g_prio256 = read_prio_env();
+static const int g_mode256 = read_mode_env();   // -1: use the caller's default
 inline int read_group_env() {
     const char* v = getenv("YUME_GEMM_GROUPM");
     const int g = v ? atoi(v) : 4;
@@ -586,16 +602,18 @@ inline int read_group_env() {
 static const int g_group_m = read_group_env();
 
 template <int EPI, class ALoad>
-int launch256(const Problem& p128, const ALoad& al, const Epilogue& e, hipStream_t st, const char* what) {
+int launch256(const Problem& p128, const ALoad& al, const Epilogue& e, hipStream_t st, const char* what, int mode_default = 2) {
     Problem p = p128;
     p.tiles_m = (p.M + 255) / 256;
     p.tiles_n = (p.N + 255) / 256;
     p.group_m = g_group_m;
     dim3 grid((unsigned)(p.tiles_m * p.tiles_n)), block(NTHR256);
-    if (g_prio256)
-        hipLaunchKernelGGL((gemm256_kernel<EPI, ALoad, true>), grid, block, 0, st, p, al, e);
-    else
-        hipLaunchKernelGGL((gemm256_kernel<EPI, ALoad, false>), grid, block, 0, st, p, al, e);
+    switch (g_mode256 >= 0 ? g_mode256 : mode_default) {
+        case 0: hipLaunchKernelGGL((gemm256_kernel<EPI, ALoad, 0>), grid, block, 0, st, p, al, e); break;
+        case 1: hipLaunchKernelGGL((gemm256_kernel<EPI, ALoad, 1>), grid, block, 0, st, p, al, e); break;
+        case 3: hipLaunchKernelGGL((gemm256_kernel<EPI, ALoad, 3>), grid, block, 0, st, p, al, e); break;
+        default: hipLaunchKernelGGL((gemm256_kernel<EPI, ALoad, 2>), grid, block, 0, st, p, al, e); break;
+    }
     YUME_CHECK_LAUNCH(what);
     return YUME_OK;
 }
