@@ -92,15 +92,20 @@ class VaeEngine:
 
     def _update_cache(self, cache, name, x):
         """cache[name] <- last two frames of (previous cache ++ x); created zero-filled on first use."""
+        if x.shape[0] >= 2:
+            # no copy: the last two frames of this chunk's input ARE the next chunk's cache (x is never written again;
+            # holding the view keeps it alive — 288 GB of HBM make that free)
+            cache[name] = x[-2:]
+            return
         c = cache.get(name)
         if c is None:
             c = torch.zeros((2,) + tuple(x.shape[1:]), dtype=torch.bfloat16, device=self.dev)
-            cache[name] = c
-        if x.shape[0] >= 2:
-            c.copy_(x[-2:])
         else:
-            c[0].copy_(c[1])
-            c[1].copy_(x[0])
+            c = torch.stack((c[1], x[0]))      # [previous last frame, this frame] in fresh memory (c may be a view)
+            cache[name] = c
+            return
+        c[1].copy_(x[0])
+        cache[name] = c
 
     def _conv3(self, name, x, cache, add=None):
         """CausalConv3d with a temporal kernel (3x3x3 or (3,1,1)), stride 1: reads cache[name], then updates it."""
