@@ -83,6 +83,71 @@ struct ConvA {
     }
 };
 
+
+// Fast path for Cin % 64 == 0 without the folded upsample: a whole 64-wide K tile then lies inside ONE tap, so the tap
+// state (dt, dh, dw, channel offset) is wave-uniform (scalar registers) and the per-row work per K tile shrinks to a
+// validity-bit test, one compare and a 64-bit add: every row keeps the address of its tap-(0,0,0) source element and a
+// 27-bit mask of the spatially valid taps; frames before the chunk (ti < 0) are the same offset from the cache base.
+struct ConvAFast {
+    const unsigned short* x;
+    const unsigned short* cache;
+    const unsigned short* zero;
+    int64_t ldc;
+    int Tin, Hin, Win, Cin;
+    int To, Ho, Wo, M;
+    int kt, kh, kw, st, sh, sw, pt, ph, pw, ups;
+    // per-thread state
+    const unsigned short* xbase[4];
+    unsigned mask[4];
+    int t0[4];
+    // uniform state
+    int cin, dt, dh, dw, tap;
+
+    __device__ __forceinline__ void init(int m0, int tid, int rpr = 32) {
+        const int lc = (tid & 7) ^ ((tid >> 3) & 7);
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            int m = m0 + rr * rpr + (tid >> 3);
+            m = m < M ? m : M - 1;
+            const int wo = m % Wo;
+            const int ho = (m / Wo) % Ho;
+            const int to = m / (Wo * Ho);
+            const int tt = to * st - pt, hh = ho * sh - ph, ww = wo * sw - pw;
+            t0[rr] = tt;
+            xbase[rr] = x + (((int64_t)tt * Hin + hh) * Win + ww) * ldc + lc * 8;   // may point outside; only used when valid
+            unsigned mk = 0;
+            for (int a = 0; a < kh; ++a)
+                for (int b = 0; b < kw; ++b)
+                    if (hh + a >= 0 && hh + a < Hin && ww + b >= 0 && ww + b < Win) mk |= 1u << (a * kw + b);
+            mask[rr] = mk;
+        }
+        cin = 0; dt = 0; dh = 0; dw = 0; tap = 0;
+    }
+    __device__ __forceinline__ const unsigned short* src(int rr, int /*kt_unused*/) const {
+        // uniform: offset of tap (dt,dh,dw) and of the cache frames relative to x
+        const int64_t soff = (((int64_t)dt * Hin + dh) * Win + dw) * ldc + cin;
+        const int ti = t0[rr] + dt;
+        const bool neg = ti < 0;
+        bool ok = dt < kt && ((mask[rr] >> (dh * kw + dw)) & 1u);
+        const unsigned short* ptr = xbase[rr] + soff;
+        if (neg) {
+            ok = ok && cache != nullptr;
+            ptr += (cache - x) + (int64_t)2 * Hin * Win * ldc;
+        }
+        return ok ? ptr : zero;
+    }
+    __device__ __forceinline__ void advance() {
+        cin += BK;
+        if (cin >= Cin) {
+            cin = 0;
+            if (++dw == kw) {
+                dw = 0;
+                if (++dh == kh) { dh = 0; ++dt; }
+            }
+        }
+    }
+};
+
 }  // namespace
 
 extern "C" int yume_conv3d_cl(const void* x, const void* cache, int64_t ldc, int64_t Tin, int64_t Hin, int64_t Win,
@@ -124,6 +189,26 @@ extern "C" int yume_conv3d_cl(const void* x, const void* cache, int64_t ldc, int
     e.hw = (int)(Ho * Wo);
     hipStream_t s = (hipStream_t)stream;
     const bool big = use_256(p, variant, true);
+    if ((Cin % BK) == 0 && !ups && kh * kw <= 32) {
+        ConvAFast af = {};
+        af.x = al.x; af.cache = al.cache; af.zero = al.zero; af.ldc = al.ldc;
+        af.Tin = al.Tin; af.Hin = al.Hin; af.Win = al.Win; af.Cin = al.Cin;
+        af.To = al.To; af.Ho = al.Ho; af.Wo = al.Wo; af.M = al.M;
+        af.kt = kt; af.kh = kh; af.kw = kw; af.st = st; af.sh = sh; af.sw = sw; af.pt = pt; af.ph = ph; af.pw = pw; af.ups = 0;
+        switch (epi) {
+            case YUME_EPI_BF16: return big ? launch256<YUME_EPI_BF16>(p, af, e, s, "conv3d_cl", 0) : launch<YUME_EPI_BF16>(p, af, e, s, "conv3d_cl");
+            case YUME_EPI_F32: return big ? launch256<YUME_EPI_F32>(p, af, e, s, "conv3d_cl", 0) : launch<YUME_EPI_F32>(p, af, e, s, "conv3d_cl");
+            case YUME_CONV_EPI_ADD:
+                YUME_REQUIRE(add != nullptr && (ldadd % 4) == 0, "conv3d_cl: ADD epilogue needs an addend with ldadd %% 4 == 0");
+                return big ? launch256<EPI_BF16_ADD>(p, af, e, s, "conv3d_cl", 0) : launch<EPI_BF16_ADD>(p, af, e, s, "conv3d_cl");
+            case YUME_CONV_EPI_TSPLIT:
+                YUME_REQUIRE((Cout % 8) == 0, "conv3d_cl: TSPLIT needs an even channel split");
+                return big ? launch256<EPI_BF16_TSPLIT>(p, af, e, s, "conv3d_cl", 0) : launch<EPI_BF16_TSPLIT>(p, af, e, s, "conv3d_cl");
+            default:
+                yume_set_error("conv3d_cl: unknown epilogue %d", epi);
+                return YUME_EINVAL;
+        }
+    }
     switch (epi) {
         case YUME_EPI_BF16: return big ? launch256<YUME_EPI_BF16>(p, al, e, s, "conv3d_cl", 0) : launch<YUME_EPI_BF16>(p, al, e, s, "conv3d_cl");
         case YUME_EPI_F32: return big ? launch256<YUME_EPI_F32>(p, al, e, s, "conv3d_cl", 0) : launch<YUME_EPI_F32>(p, al, e, s, "conv3d_cl");
