@@ -298,21 +298,31 @@ constexpr int V2_BUF = 2 * K_TILE_BYTES;      // K 16 KiB + V^T 16 KiB (128-byte
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((address_space(1))) const void gbl_cvoid_t;
 
-__device__ __forceinline__ void dma_tile(const AttnArgs& p, int h, int j0, char* buf, int tid, int wave) {
+// per-thread source pointers of the 8 LDS-DMA pieces of a tile (4 K rounds, 4 V^T rounds), advanced by one tile per use
+struct DmaPtrs {
+    const unsigned short* k[4];
+    const unsigned short* v[4];
+};
+__device__ __forceinline__ void dma_init(DmaPtrs& dp, const AttnArgs& p, int h, int tid) {
 #pragma unroll
-    for (int rr = 0; rr < 4; ++rr) {          // K: 64 rows x 16 chunks
-        const int r = rr * 16 + (tid >> 4);
-        int key = j0 + r;
-        key = key < p.Lk ? key : p.Lk - 1;
-        const unsigned short* g = p.K + (int64_t)key * p.ldk + h * D + (((tid & 15) ^ (r & 15)) << 3);
-        __builtin_amdgcn_global_load_lds((gbl_cvoid_t*)g, (lds_void_t*)(buf + rr * 4096 + wave * 1024), 16, 0, 0);
+    for (int rr = 0; rr < 4; ++rr) {
+        const int r = rr * 16 + (tid >> 4);            // K: 64 rows x 16 chunks; full tiles only -> no clamp needed
+        dp.k[rr] = p.K + (int64_t)r * p.ldk + h * D + (((tid & 15) ^ (r & 15)) << 3);
+        const int d = rr * 32 + (tid >> 3);            // V^T: 128 rows x 8 chunks
+        dp.v[rr] = p.Vt + (int64_t)(h * D + d) * p.ldvt + (((tid & 7) ^ ((d >> 1) & 7)) << 3);
+    }
+}
+__device__ __forceinline__ void dma_tile(DmaPtrs& dp, int64_t kstep, char* buf, int wave) {
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+        __builtin_amdgcn_global_load_lds((gbl_cvoid_t*)dp.k[rr], (lds_void_t*)(buf + rr * 4096 + wave * 1024), 16, 0, 0);
+        dp.k[rr] += kstep;
     }
     char* vb = buf + K_TILE_BYTES;
 #pragma unroll
-    for (int rr = 0; rr < 4; ++rr) {          // V^T: 128 rows x 8 chunks
-        const int d = rr * 32 + (tid >> 3);
-        const unsigned short* g = p.Vt + (int64_t)(h * D + d) * p.ldvt + j0 + (((tid & 7) ^ ((d >> 1) & 7)) << 3);
-        __builtin_amdgcn_global_load_lds((gbl_cvoid_t*)g, (lds_void_t*)(vb + rr * 4096 + wave * 1024), 16, 0, 0);
+    for (int rr = 0; rr < 4; ++rr) {
+        __builtin_amdgcn_global_load_lds((gbl_cvoid_t*)dp.v[rr], (lds_void_t*)(vb + rr * 4096 + wave * 1024), 16, 0, 0);
+        dp.v[rr] += KT;
     }
 }
 
@@ -333,18 +343,18 @@ __device__ __forceinline__ void stage_store_v2(const Stage& s, char* buf, int ti
 
 template <bool MASK>
 __device__ __forceinline__ void tile_body_v2(const char* kb, const AttnArgs& p, const bf16x8_t (&qf)[8],
-                                             f32x16 (&oacc)[4], float& m_run, float& l_run, int j0, int ql, int hi) {
+                                             f32x16 (&oacc)[4], float& m_run, float& l_run, int j0, int ql, int hi,
+                                             const int (&koff)[8], const int (&voff)[4]) {
     const char* vb = kb + K_TILE_BYTES;
     f32x16 sacc[2];
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) sacc[b][r] = 0.f;
-        const int row = 32 * b + ql;
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) {
-            const int c = 2 * ks + hi;
-            const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(kb + row * 256 + ((c ^ (row & 15)) << 4));
+            // row 32b + ql has the same swizzle as row ql: one per-lane offset per k-step + an immediate
+            const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(kb + koff[ks] + b * (32 * 256));
             sacc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sacc[b], 0, 0, 0);
         }
     }
@@ -401,12 +411,10 @@ __device__ __forceinline__ void tile_body_v2(const char* kb, const AttnArgs& p, 
     // ---- O^T += V^T . P^T ---- (an explicit one-d-block-ahead fragment prefetch was measured: no gain, dropped)
 #pragma unroll
     for (int db = 0; db < 4; ++db) {
-        const int d = 32 * db + ql;
-        const char* vrow = vb + d * 128;
-        const int sw = (d >> 1) & 7;
 #pragma unroll
         for (int sg = 0; sg < 4; ++sg) {
-            const bf16x8_t vf = *reinterpret_cast<const bf16x8_t*>(vrow + (((2 * sg + hi) ^ sw) << 4));
+            // row 32db + ql swizzles like row ql ((d >> 1) & 7 is unchanged by + 32db)
+            const bf16x8_t vf = *reinterpret_cast<const bf16x8_t*>(vb + voff[sg] + db * (32 * 128));
             oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[sg], oacc[db], 0, 0, 0);
         }
     }
@@ -445,6 +453,15 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel_v2(AttnArgs p) {
         for (int r = 0; r < 16; ++r) oacc[i][r] = 0.f;
     float m_run = NEG_BIG, l_run = 0.f;
 
+    int koff[8], voff[4];
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) koff[ks] = ql * 256 + (((2 * ks + hi) ^ (ql & 15)) << 4);
+#pragma unroll
+    for (int sg = 0; sg < 4; ++sg) voff[sg] = ql * 128 + (((2 * sg + hi) ^ ((ql >> 1) & 7)) << 4);
+    DmaPtrs dp;
+    dma_init(dp, p, h, tid);
+    const int64_t kstep = (int64_t)KT * p.ldk;
+
     const int nt = (p.Lk + KT - 1) / KT;
     const bool ragged = (p.Lk % KT) != 0;          // then the LAST tile takes the register path
     if (nt == 1 && ragged) {
@@ -452,7 +469,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel_v2(AttnArgs p) {
         stage_load(st, p, h, 0, tid);
         stage_store_v2(st, smem, tid);
     } else {
-        dma_tile(p, h, 0, smem, tid, wave);
+        dma_tile(dp, kstep, smem, wave);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -463,11 +480,11 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel_v2(AttnArgs p) {
         char* nb = smem + (cur ^ 1) * V2_BUF;
         const bool has_next = t + 1 < nt;
         const bool next_reg = has_next && ragged && (t + 2 == nt);
-        if (has_next && !next_reg) dma_tile(p, h, (t + 1) * KT, nb, tid, wave);
+        if (has_next && !next_reg) dma_tile(dp, kstep, nb, wave);
         if (!has_next && ragged)
-            tile_body_v2<true>(kb, p, qf, oacc, m_run, l_run, t * KT, ql, hi);
+            tile_body_v2<true>(kb, p, qf, oacc, m_run, l_run, t * KT, ql, hi, koff, voff);
         else
-            tile_body_v2<false>(kb, p, qf, oacc, m_run, l_run, t * KT, ql, hi);
+            tile_body_v2<false>(kb, p, qf, oacc, m_run, l_run, t * KT, ql, hi, koff, voff);
         if (next_reg) {
             Stage st;
             stage_load(st, p, h, (t + 1) * KT, tid);

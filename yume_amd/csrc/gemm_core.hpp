@@ -623,7 +623,10 @@ inline bool use_256(const Problem& p, int variant, bool split_ok) {
     if (variant == 1 || !split_ok) return false;
     if (variant == 2) return true;
     const int64_t t256 = (int64_t)((p.M + 255) / 256) * ((p.N + 255) / 256);
-    return t256 >= 192;
+    if (t256 < 192) return false;                      // does not fill the 256 CUs
+    // padded work of both tilings; the 256^2 pipeline is worth ~1.25x per flop (measured 1.15-1.3 PF vs 0.85-1.0 PF)
+    const int64_t t128 = (int64_t)((p.M + 127) / 128) * ((p.N + 127) / 128);
+    return (double)t256 * 4.0 / 1.25 <= (double)t128;
 }
 
 template <int EPI, class ALoad>
