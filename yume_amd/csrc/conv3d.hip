@@ -29,7 +29,7 @@ struct ConvA {
     int t0[4], h0[4], w0[4];
     int cin, dt, dh, dw;
 
-    __device__ __forceinline__ void init(int m0, int tid, int rpr = 32) {
+    __device__ __forceinline__ void init(int m0, int tid, int rpr = 32, int kshift = 0) {
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
             int m = m0 + rr * rpr + (tid >> 3);
@@ -41,7 +41,7 @@ struct ConvA {
             h0[rr] = ho * sh - ph;
             w0[rr] = wo * sw - pw;
         }
-        const int lc = (tid & 7) ^ ((tid >> 3) & 7);   // logical 16-byte chunk of this thread (same for its 4 rows)
+        const int lc = (tid & 7) ^ (((tid >> 3) >> kshift) & 7);   // logical 16-byte chunk of this thread (same for its 4 rows)
         const int k = lc * 8;
         int tap = k / Cin;
         cin = k - tap * Cin;
@@ -103,8 +103,8 @@ struct ConvAFast {
     // uniform state
     int cin, dt, dh, dw, tap;
 
-    __device__ __forceinline__ void init(int m0, int tid, int rpr = 32) {
-        const int lc = (tid & 7) ^ ((tid >> 3) & 7);
+    __device__ __forceinline__ void init(int m0, int tid, int rpr = 32, int kshift = 0) {
+        const int lc = (tid & 7) ^ (((tid >> 3) >> kshift) & 7);
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
             int m = m0 + rr * rpr + (tid >> 3);

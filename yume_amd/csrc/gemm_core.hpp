@@ -55,13 +55,14 @@ typedef __attribute__((address_space(1))) const void gbl_cvoid;
 struct PlainA {
     const unsigned short* A; int64_t lda; int M;
     const unsigned short* rowp[4];
-    __device__ __forceinline__ void init(int m0, int tid, int rpr = 32) {
+    // kshift selects the LDS swizzle key of a row: (row >> kshift) & 7 (0 for the 16x16 fragments, 1 for 32x32 ones)
+    __device__ __forceinline__ void init(int m0, int tid, int rpr = 32, int kshift = 0) {
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
             const int r = rr * rpr + (tid >> 3);
             int gr = m0 + r;
             gr = gr < M ? gr : M - 1;
-            rowp[rr] = A + (int64_t)gr * lda + (((tid & 7) ^ (r & 7)) << 3);
+            rowp[rr] = A + (int64_t)gr * lda + (((tid & 7) ^ ((r >> kshift) & 7)) << 3);
         }
     }
     __device__ __forceinline__ const unsigned short* src(int rr, int kt) const { return rowp[rr] + kt * BK; }
@@ -330,6 +331,68 @@ __device__ __forceinline__ void stage_half_b(const unsigned short* const (&wrow)
         __builtin_amdgcn_sched_barrier(0);                       \
     }
 
+// ---- vector epilogue stores straight from accumulators (256^2 kernels) ----
+// v = C[m][n .. n+3] (row-major destinations)
+template <int EPI>
+__device__ __forceinline__ void store_row4(f32x4 v, int m, int n, const Problem& p, const Epilogue& e) {
+    if (e.bias) v += *reinterpret_cast<const f32x4*>(e.bias + n);
+    if (EPI == YUME_EPI_F32) {
+        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(e.out) + (int64_t)m * e.ldo + n) = v;
+    } else if (EPI == YUME_EPI_RESID) {
+        float* xo = reinterpret_cast<float*>(e.out) + (int64_t)m * e.ldo + n;
+        f32x4 x = *reinterpret_cast<const f32x4*>(xo);
+        if (e.gate) {
+            const int64_t row = e.row_idx ? (int64_t)e.row_idx[m] : 0;
+            x += v * *reinterpret_cast<const f32x4*>(e.gate + row * e.gate_stride + n);
+        } else {
+            x += v;
+        }
+        *reinterpret_cast<f32x4*>(xo) = x;
+    } else {
+        if (EPI == YUME_EPI_BF16_GELU) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = gelu_tanh(v[q]);
+        }
+        if (EPI == YUME_EPI_BF16_GELU_ERF) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = 0.5f * v[q] * (1.0f + erff(v[q] * 0.7071067811865476f));
+        }
+        if (EPI == EPI_BF16_ADD) {
+            const u32x2 a2 = *reinterpret_cast<const u32x2*>(e.add + (int64_t)m * e.ldadd + n);
+            v[0] += bf16_to_f32((unsigned short)(a2[0] & 0xffffu));
+            v[1] += bf16_to_f32((unsigned short)(a2[0] >> 16));
+            v[2] += bf16_to_f32((unsigned short)(a2[1] & 0xffffu));
+            v[3] += bf16_to_f32((unsigned short)(a2[1] >> 16));
+        }
+        int64_t orow = m;
+        int ocol = n;
+        if (EPI == EPI_BF16_TSPLIT) {
+            const int ch = p.N >> 1;
+            const int j = n >= ch ? 1 : 0;
+            const int t = m / e.hw;
+            orow = (int64_t)m + (int64_t)(t + j) * e.hw;
+            ocol = n - j * ch;
+        }
+        u32x2 o;
+        o[0] = pack_bf16x2(v[0], v[1]);
+        o[1] = pack_bf16x2(v[2], v[3]);
+        *reinterpret_cast<u32x2*>(reinterpret_cast<unsigned short*>(e.out) + orow * e.ldo + ocol) = o;
+    }
+}
+// v = C[m .. m+3][n] -> K-major outT[n - n_split][m .. m+3]
+__device__ __forceinline__ void store_col4(f32x4 v, int m, int n, const Problem& p, const Epilogue& e) {
+    const float bn = e.bias ? e.bias[n] : 0.f;
+    unsigned short* dst = e.outT + (int64_t)(n - e.n_split) * e.ldt + m;
+    if (m + 3 < p.M) {
+        u32x2 o;
+        o[0] = pack_bf16x2(v[0] + bn, v[1] + bn);
+        o[1] = pack_bf16x2(v[2] + bn, v[3] + bn);
+        *reinterpret_cast<u32x2*>(dst) = o;
+    } else {
+        for (int q = 0; q < 4 && m + q < p.M; ++q) dst[q] = f32_to_bf16(v[q] + bn);
+    }
+}
+
 // MODE: 0 = one barrier per phase; 1 = + s_setprio(1) around the MFMA clusters; 2 = STAGGERED: a second barrier after every
 // MFMA cluster and the wr = 1 half of the waves running one barrier behind the wr = 0 half, so that of the two waves
 // sharing a SIMD (w and w+4) one is in its MFMA cluster while the other issues its ds_reads / LDS-DMA (+ setprio);
@@ -499,65 +562,16 @@ __device__ __forceinline__ void gemm256_body(const Problem& p, ALoad& al, const 
                     if (SWAP) {
                         const int m = mb + l15, n = nb + 4 * l4;        // v = C[m][n .. n+3]
                         if (m >= p.M || n >= p.N) continue;
-                        if (e.bias) v += *reinterpret_cast<const f32x4*>(e.bias + n);
-                        if (EPI == YUME_EPI_F32) {
-                            *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(e.out) + (int64_t)m * e.ldo + n) = v;
-                        } else if (EPI == YUME_EPI_RESID) {
-                            float* xo = reinterpret_cast<float*>(e.out) + (int64_t)m * e.ldo + n;
-                            f32x4 x = *reinterpret_cast<const f32x4*>(xo);
-                            if (e.gate) {
-                                const int64_t row = e.row_idx ? (int64_t)e.row_idx[m] : 0;
-                                x += v * *reinterpret_cast<const f32x4*>(e.gate + row * e.gate_stride + n);
-                            } else {
-                                x += v;
-                            }
-                            *reinterpret_cast<f32x4*>(xo) = x;
-                        } else {
-                            if (EPI == YUME_EPI_BF16_GELU) {
-#pragma unroll
-                                for (int q = 0; q < 4; ++q) v[q] = gelu_tanh(v[q]);
-                            }
-                            if (EPI == YUME_EPI_BF16_GELU_ERF) {
-#pragma unroll
-                                for (int q = 0; q < 4; ++q) v[q] = 0.5f * v[q] * (1.0f + erff(v[q] * 0.7071067811865476f));
-                            }
-                            if (EPI == EPI_BF16_ADD) {
-                                const u32x2 a2 = *reinterpret_cast<const u32x2*>(e.add + (int64_t)m * e.ldadd + n);
-                                v[0] += bf16_to_f32((unsigned short)(a2[0] & 0xffffu));
-                                v[1] += bf16_to_f32((unsigned short)(a2[0] >> 16));
-                                v[2] += bf16_to_f32((unsigned short)(a2[1] & 0xffffu));
-                                v[3] += bf16_to_f32((unsigned short)(a2[1] >> 16));
-                            }
-                            int64_t orow = m;
-                            int ocol = n;
-                            if (EPI == EPI_BF16_TSPLIT) {
-                                const int ch = p.N >> 1;
-                                const int j = n >= ch ? 1 : 0;
-                                const int t = m / e.hw;
-                                orow = (int64_t)m + (int64_t)(t + j) * e.hw;
-                                ocol = n - j * ch;
-                            }
-                            u32x2 o;
-                            o[0] = pack_bf16x2(v[0], v[1]);
-                            o[1] = pack_bf16x2(v[2], v[3]);
-                            *reinterpret_cast<u32x2*>(reinterpret_cast<unsigned short*>(e.out) + orow * e.ldo + ocol) = o;
-                        }
+                        store_row4<EPI>(v, m, n, p, e);
                     } else {
                         const int m = mb + 4 * l4, n = nb + l15;        // v = C[m .. m+3][n]  -> outT[n - n_split][m .. m+3]
                         if (m >= p.M || n >= p.N) continue;
-                        const float bn = e.bias ? e.bias[n] : 0.f;
-                        unsigned short* dst = e.outT + (int64_t)(n - e.n_split) * e.ldt + m;
-                        if (m + 3 < p.M) {
-                            u32x2 o;
-                            o[0] = pack_bf16x2(v[0] + bn, v[1] + bn);
-                            o[1] = pack_bf16x2(v[2] + bn, v[3] + bn);
-                            *reinterpret_cast<u32x2*>(dst) = o;
-                        } else {
-                            for (int q = 0; q < 4 && m + q < p.M; ++q) dst[q] = f32_to_bf16(v[q] + bn);
-                        }
+                        store_col4(v, m, n, p, e);
                     }
                 }
 }
+
+// (a v_mfma_f32_32x32x16_bf16 variant of this schedule was built and measured: 13 % slower — dropped)
 
 template <int EPI, class ALoad, int MODE>
 __global__ __launch_bounds__(NTHR256, 2) void gemm256_kernel(Problem p, ALoad al, Epilogue e) {
@@ -577,14 +591,10 @@ __global__ __launch_bounds__(NTHR256, 2) void gemm256_kernel(Problem p, ALoad al
     const int tm = first_m + (wg % width) % gsz;
     const int tn = (wg % width) / gsz;
     const int m0 = tm * 256, n0 = tn * 256;
-    if (EPI == YUME_EPI_BF16_SPLITT) {
-        if (n0 >= e.n_split)
-            gemm256_body<EPI, ALoad, MODE, false>(p, al, e, smem, m0, n0);
-        else
-            gemm256_body<EPI, ALoad, MODE, true>(p, al, e, smem, m0, n0);
-    } else {
+    if (EPI == YUME_EPI_BF16_SPLITT && n0 >= e.n_split)
+        gemm256_body<EPI, ALoad, MODE, false>(p, al, e, smem, m0, n0);
+    else
         gemm256_body<EPI, ALoad, MODE, true>(p, al, e, smem, m0, n0);
-    }
 }
 
 // schedule variant of the 256^2 kernel (see MODE above); env YUME_GEMM_MODE overrides for A/B runs
