@@ -167,3 +167,38 @@ def test_long_video_loop_with_vae():
     lat, vids = sampling.long_video_5b(m, vae, hist, ctxs, steps=2, generator=g)
     assert lat.shape == (48, 5 + 16, 4, 6) and torch.isfinite(lat).all()
     assert len(vids) == 2 and vids[0].shape == (3, 29, 64, 96) and all(torch.isfinite(v).all() for v in vids)
+
+
+@pytest.mark.parametrize("name", ["dit_wan23_packed_f13", "dit_wan_packed_f13"])
+def test_context_cache_is_bit_identical(name):
+    """caching the step-invariant text/CLIP embeddings and cross-attention K/V must not change a bit, and
+    must be invalidated when the conditioning tensor changes (new object or in-place update)."""
+    fx = load_golden(name)
+    fam = fx["family"]
+    sd = synth.make_dit_state_dict(fx["cfg"], fam, fx["seed"])
+    m = build_model(fam, fx["cfg"], sd)
+    inp = {k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in fx["inputs"].items()}
+
+    def run(t_scale=1.0, ctx=None):
+        c = inp["context"] if ctx is None else ctx
+        if fam == "wan23":
+            return m([inp["x"]], t=fx["t"].to(DEV) * t_scale, context=[c], seq_len=fx["seq_len"], latent_frame_zero=fx["lfz"], flag=True)[0]
+        return m([inp["x"]], t=fx["t"].to(DEV) * t_scale, context=[c], seq_len=fx["seq_len"], clip_fea=inp["clip_fea"], y=[inp["y"]],
+                 rand_num_img=0.6, latent_frame_zero=fx["lfz"])[0]
+
+    base1, base2 = run(1.0).clone(), run(0.5).clone()
+    m.engine.cache_context = True
+    assert torch.equal(run(1.0), base1)          # fills the cache
+    assert torch.equal(run(0.5), base2)          # hit: another timestep, same conditioning
+    assert torch.equal(run(1.0), base1)
+    ctx2 = inp["context"] * 1.5                  # new conditioning object -> miss
+    m.engine.cache_context = False
+    want2 = run(1.0, ctx2).clone()
+    m.engine.cache_context = True
+    assert torch.equal(run(1.0, ctx2), want2)
+    ctx2.mul_(0.5)                               # in-place update bumps the version -> miss
+    m.engine.cache_context = False
+    want3 = run(1.0, ctx2).clone()
+    m.engine.cache_context = True
+    assert torch.equal(run(1.0, ctx2), want3)
+    assert not torch.equal(want3, want2)

@@ -38,6 +38,12 @@ class DiTEngine:
         self._ws = {}
         self._plan_cache = {}
         self.prof = None   # list collecting (start, end) HIP event pairs of the ffn.0 GEMM when profiling
+        # the text / CLIP embeddings and every block's cross-attention K, V^T depend only on the
+        # conditioning, not on the latent or the timestep; with cache_context they are computed once per conditioning
+        # tensor (same object, same version) instead of once per denoise step. Off by default = the reference's work.
+        self.cache_context = False
+        self._ctx_key = None
+        self._ctx_refs = None
 
     # ------------------------------------------------------------------ weights
     def _param_key(self):
@@ -209,17 +215,20 @@ class DiTEngine:
         ops.gemm_bf16(h, w3, b3, y, EPI_F32)
         ops.adaln_modulate(y, l4w, l4b, 0, None, False, out_rows, 0, eps=1e-5)
 
-    def _cross(self, hc, ctx_rows, nk, wkv, bkv, nk_w, ac, L, accumulate):
-        """one cross-attention over ctx_rows (bf16 [nk, C]); result into ac (bf16 [L, C])."""
+    def _cross(self, hc, ctx_rows, nk, wkv, bkv, nk_w, ac, L, accumulate, blk, fresh):
+        """one cross-attention over ctx_rows (bf16 [nk, C]); result into ac (bf16 [L, C]). With cache_context the
+        projected K / V^T live in per-block buffers and are recomputed only when the conditioning changed."""
         C, H = self.model.dim, self.model.num_heads
         eps = self.model.eps
-        kc = self._buf(f"kc_{nk}", (nk, C), torch.bfloat16)
-        vct = self._buf(f"vct_{nk}", (C, _round_up(nk, 8)), torch.bfloat16)
-        ops.gemm_bf16(ctx_rows, wkv, bkv, kc, EPI_BF16_SPLITT, out_t=vct, n_split=C)
-        ops.rmsnorm_rope(kc, C, 1, nk_w, eps)
+        tag = f"{nk}_{blk}" if self.cache_context else f"{nk}"
+        kc = self._buf(f"kc_{tag}", (nk, C), torch.bfloat16)
+        vct = self._buf(f"vct_{tag}", (C, _round_up(nk, 8)), torch.bfloat16)
+        if fresh:
+            ops.gemm_bf16(ctx_rows, wkv, bkv, kc, EPI_BF16_SPLITT, out_t=vct, n_split=C)
+            ops.rmsnorm_rope(kc, C, 1, nk_w, eps)
         ops.attn_fwd(hc, kc, vct, ac, L, nk, H, accumulate=accumulate)
 
-    def _blocks(self, xs, L, tab, row_idx, R, rope, n_rope, ctx, n_img):
+    def _blocks(self, xs, L, tab, row_idx, R, rope, n_rope, ctx, n_img, ctx_fresh=True):
         """xs fp32 [L, C] in/out. tab fp32 [nb, R, 6, C]; rope fp32 [n_rope, 64, 2] (n_rope == L here)."""
         m = self.model
         C, H, Fd, eps = m.dim, m.num_heads, m.ffn_dim, m.eps
@@ -252,9 +261,9 @@ class DiTEngine:
             ops.gemm_bf16(h, d["wq_c"], d["bq_c"], qk[:, :C], EPI_BF16)
             ops.rmsnorm_rope(qk[:, :C], C, 1, d["nq_c"], eps)
             ntxt = ctx.shape[0] - n_img
-            self._cross(qk[:, :C], ctx[n_img:], ntxt, d["wkv_c"], d["bkv_c"], d["nk_c"], att, L, False)
+            self._cross(qk[:, :C], ctx[n_img:], ntxt, d["wkv_c"], d["bkv_c"], d["nk_c"], att, L, False, i, ctx_fresh)
             if n_img:
-                self._cross(qk[:, :C], ctx[:n_img], n_img, d["wkv_i"], d["bkv_i"], d["nk_i"], att, L, True)
+                self._cross(qk[:, :C], ctx[:n_img], n_img, d["wkv_i"], d["bkv_i"], d["nk_i"], att, L, True, i, ctx_fresh)
             ops.gemm_bf16(att, d["wo_c"], d["bo_c"], xs, EPI_RESID)
             # --- FFN
             ops.adaln_modulate(xs, scale_ff, shift_ff, ts, row_idx, True, h, 0, eps)
@@ -360,10 +369,22 @@ class DiTEngine:
                 raise RuntimeError("clip_fea is required by the i2v model")
             n_img = clip_fea.reshape(-1, clip_fea.shape[-1]).shape[0]
         ctx = self._buf("ctx", (n_img + m.text_len, C), torch.bfloat16)
-        if n_img:
-            self._img_ctx(clip_fea, ctx[:n_img])
-        self._text_ctx(context, ctx[n_img:])
+        ctx_fresh = True
+        if self.cache_context:
+            # storage address + version counter + shape (views of one tensor share all three); holding the references below
+            # keeps those addresses from being handed to another tensor while the entry is live
+            key = (context.data_ptr(), context._version, tuple(context.shape),
+                   None if clip_fea is None else (clip_fea.data_ptr(), clip_fea._version, tuple(clip_fea.shape)),
+                   self._packed_key)
+            ctx_fresh = key != self._ctx_key
+            self._ctx_key, self._ctx_refs = key, (context, clip_fea)
+        else:
+            self._ctx_key = None
+        if ctx_fresh:
+            if n_img:
+                self._img_ctx(clip_fea, ctx[:n_img])
+            self._text_ctx(context, ctx[n_img:])
 
-        self._blocks(xs, L, tab.view(nb, R, 6, C), row_idx, R, rope, L, ctx, n_img)
+        self._blocks(xs, L, tab.view(nb, R, 6, C), row_idx, R, rope, L, ctx, n_img, ctx_fresh)
         ridx_new = row_idx[n_hist:] if row_idx is not None else None
         return self._head(xs[n_hist:], ridx_new, e, R, grid)
