@@ -464,13 +464,13 @@ __device__ __forceinline__ void gemm256_body(const Problem& p, ALoad& al, const 
     for (int t = 0; t < nk; ++t) {
         char* cs = (t & 1) ? s1 : s0;          // slot of K tile t (and t+2)
         char* ns = (t & 1) ? s0 : s1;          // slot of K tile t+1
-        bf16x8_t a[4][2], b[2][2];             // [mi][ks], [ni][ks]
+        bf16x8_t a[4][2], b[2][2], b0[2][2];   // [mi][ks], [ni][ks]; b0 = the B0 fragments, kept from P1 for P4
 
         // ---------------- P1: quadrant (0,0) ----------------
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) b[ni][ks] = lds_frag(cs + OB0, brow + ni * 16, ks * 4 + lch);
+            for (int ks = 0; ks < 2; ++ks) b0[ni][ks] = lds_frag(cs + OB0, brow + ni * 16, ks * 4 + lch);
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
@@ -483,8 +483,8 @@ __device__ __forceinline__ void gemm256_body(const Problem& p, ALoad& al, const 
             for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
                 for (int ni = 0; ni < 2; ++ni)
-                    acc[0][0][mi][ni] = SWAP ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[ni][ks], a[mi][ks], acc[0][0][mi][ni], 0, 0, 0)
-                                             : __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mi][ks], b[ni][ks], acc[0][0][mi][ni], 0, 0, 0);
+                    acc[0][0][mi][ni] = SWAP ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0[ni][ks], a[mi][ks], acc[0][0][mi][ni], 0, 0, 0)
+                                             : __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mi][ks], b0[ni][ks], acc[0][0][mi][ni], 0, 0, 0);
         YUME_PHASE_END();
 
         // ---------------- P2: quadrant (0,1) ----------------
@@ -521,11 +521,7 @@ __device__ __forceinline__ void gemm256_body(const Problem& p, ALoad& al, const 
                                              : __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mi][ks], b[ni][ks], acc[1][1][mi][ni], 0, 0, 0);
         YUME_PHASE_END();
 
-        // ---------------- P4: quadrant (1,0) ----------------
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) b[ni][ks] = lds_frag(cs + OB0, brow + ni * 16, ks * 4 + lch);
+        // ---------------- P4: quadrant (1,0) ---------------- (B0 fragments still in registers from P1)
         if (t + 2 < nk) {
             stage_half_a(al, 1, t + 2, cs + OA1, wave);
             al.advance();
@@ -540,8 +536,8 @@ __device__ __forceinline__ void gemm256_body(const Problem& p, ALoad& al, const 
             for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
                 for (int ni = 0; ni < 2; ++ni)
-                    acc[1][0][mi][ni] = SWAP ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[ni][ks], a[mi][ks], acc[1][0][mi][ni], 0, 0, 0)
-                                             : __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mi][ks], b[ni][ks], acc[1][0][mi][ni], 0, 0, 0);
+                    acc[1][0][mi][ni] = SWAP ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0[ni][ks], a[mi][ks], acc[1][0][mi][ni], 0, 0, 0)
+                                             : __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mi][ks], b0[ni][ks], acc[1][0][mi][ni], 0, 0, 0);
         YUME_PHASE_END();
     }
 
