@@ -254,6 +254,15 @@ int yume_vae_pack_input(const void* x, int in_bf16, int64_t C, int64_t T, int64_
 int yume_vae_unpack_output(const void* x, int64_t ldx, int64_t T, int64_t H, int64_t W, int64_t Cv, int ps,
                            const float* sub, const float* mul, float lo, float hi, float* out, void* stream);
 
+/* ---- post-decode frame conversion ---------------------------------------------------------------
+ * replaces: fastvideo/sample/sample_5b.py:491-500 save_video -> diffusers==0.32.0 VideoProcessor.postprocess_video
+ *           (denormalize `(x * 0.5 + 0.5).clamp(0, 1)`, then numpy_to_pil `(x * 255).round().astype("uint8")`) — the
+ *           reference does this on the host after a device->host copy of the fp32 video; here it runs on the decoder's
+ *           output in HBM and 1 byte per sample crosses PCIe instead of 4.
+ * video: fp32 [C, T, H, W] (C <= 4, T*H*W % 4 == 0) -> out: uint8 [T, H, W, C]. Bit-exact (fp32, round half to even).
+ */
+int yume_frames_u8(const float* video, int64_t C, int64_t T, int64_t H, int64_t W, void* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

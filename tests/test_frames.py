@@ -1,0 +1,66 @@
+"""Post-decode frame conversion: oracle known answers on CPU, HIP kernel bit-exact on the GPU."""
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT
+
+sys.path.insert(0, ROOT)
+from oracle import frames as oframes  # noqa: E402
+
+
+def test_oracle_known_answers():
+    # x -> round_half_even(clamp(x/2 + 1/2, 0, 1) * 255)
+    x = torch.tensor([-1.0, 1.0, 0.0, -2.0, 3.0, 1 / 255, -1 / 255, 0.5, -0.5, 2 / 255 - 1, 1 - 2 / 255, 4 / 255 - 1])
+    want = [0, 255, 128, 0, 255, 128, 127, 191, 64, 1, 254, 2]
+    # 0.0 -> 127.5 -> 128 (even); 0.5 -> 191.25 -> 191; -0.5 -> 63.75 -> 64; 1/255 -> 128.0
+    got = oframes.frames_u8(x.view(1, 1, 1, -1))
+    assert got.shape == (1, 1, 12, 1) and got.dtype == np.uint8
+    assert got.reshape(-1).tolist() == want
+    # half-way cases land on the even neighbour: (k + 0.5)/255 for even k rounds down, for odd k rounds up
+    k = torch.arange(0, 255, dtype=torch.float64)
+    xs = (((k + 0.5) / 255) * 2 - 1).float()
+    got = oframes.frames_u8(xs.view(1, 1, 1, -1)).reshape(-1).astype(int)
+    lo, hi = k.numpy().astype(int), k.numpy().astype(int) + 1
+    assert ((got == lo) | (got == hi)).all()
+
+
+def test_oracle_layout():
+    v = torch.linspace(-1, 1, 3 * 2 * 4 * 8).view(3, 2, 4, 8)
+    got = oframes.frames_u8(v)
+    assert got.shape == (2, 4, 8, 3)
+    assert got[1, 2, 3, 0] == oframes.frames_u8(v[0:1, 1:2, 2:3, 3:4]).item()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(3, 1, 4, 8), (3, 5, 64, 96), (1, 2, 6, 10), (4, 3, 16, 12), (3, 29, 176, 320)])
+def test_frames_u8_bit_exact(shape):
+    from yume_amd import video
+    g = torch.Generator().manual_seed(7)
+    v = torch.randn(shape, generator=g) * 0.8
+    flat = v.view(-1)
+    n = min(flat.numel(), 510)
+    k = torch.arange(n, dtype=torch.float64) / 2                   # every k/2 / 255: all the exact half-way points
+    flat[:n] = ((k / 255) * 2 - 1).float()
+    got = video.frames_u8(v.cuda())
+    assert got.dtype == torch.uint8 and tuple(got.shape) == (shape[1], shape[2], shape[3], shape[0])
+    assert np.array_equal(got.cpu().numpy(), oframes.frames_u8(v))
+
+
+@pytest.mark.gpu
+def test_video_processor_matches_reference_call_shape():
+    from yume_amd.video import VideoProcessor
+    v = (torch.rand(3, 5, 16, 24) * 2 - 1).cuda()
+    vp = VideoProcessor(vae_scale_factor=8)
+    pil = vp.postprocess_video(v.unsqueeze(0), output_type="pil")          # sample_5b.py:498-499
+    assert len(pil) == 1 and len(pil[0]) == 5 and pil[0][0].size == (24, 16) and pil[0][0].mode == "RGB"
+    assert np.array_equal(np.asarray(pil[0][3]), oframes.frames_u8(v.cpu())[3])
+    u8 = vp.postprocess_video(v.unsqueeze(0), output_type="uint8")
+    assert tuple(u8.shape) == (1, 5, 16, 24, 3)
+    arr = vp.postprocess_video(v.unsqueeze(0), output_type="np")
+    assert arr.shape == (1, 5, 16, 24, 3) and arr.min() >= 0 and arr.max() <= 1
+    with pytest.raises(RuntimeError):
+        from yume_amd import video
+        video.frames_u8(v.cpu())

@@ -35,6 +35,7 @@ SIGNATURES = {
     "yume_vae_avgdown_add": [_P, _L, _L, _L, _L, _L, _P, _L, _L, _I, _I, _P],
     "yume_softmax_rows": [_P, _L, _L, _L, _F, _P, _L, _P],
     "yume_vae_pack_input": [_P, _I, _L, _L, _L, _L, _I, _P, _P, _P, _L, _P],
+    "yume_frames_u8": [_P, _L, _L, _L, _L, _P, _P],
     "yume_vae_unpack_output": [_P, _L, _L, _L, _L, _L, _I, _P, _P, _F, _F, _P, _P],
 }
 _RES = {"yume_last_error": c_char_p, "yume_target_arch": c_char_p}

@@ -204,6 +204,35 @@ __global__ __launch_bounds__(256) void unpack_output_kernel(const unsigned short
     }
 }
 
+// fp32 [C, T, H, W] in [-1, 1] -> uint8 [T, H, W, C]: one thread = 4 consecutive w of all C channels
+// (C coalesced 16-byte loads, one contiguous 4*C-byte store). HBM-bound: 4 B read + 1 B written per element.
+template <int C>
+__global__ __launch_bounds__(256) void frames_u8_kernel(const float* __restrict__ x, int64_t plane /* T*H*W */, int64_t nquad,
+                                                        unsigned char* __restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nquad; i += (int64_t)gridDim.x * blockDim.x) {
+        unsigned char b[4 * C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(x + c * plane + 4 * i);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                // diffusers VideoProcessor: denormalize (x * 0.5 + 0.5).clamp(0, 1), then (x * 255).round() -> uint8 (half to even)
+                float f = __fadd_rn(__fmul_rn(v[q], 0.5f), 0.5f);
+                f = fminf(fmaxf(f, 0.f), 1.f);
+                b[q * C + c] = (unsigned char)(int)rintf(__fmul_rn(f, 255.f));
+            }
+        }
+        unsigned char* dst = out + 4 * C * i;
+        if (C == 3 || C == 1 || C == 4 || C == 2) {
+#pragma unroll
+            for (int w = 0; w < C; ++w) {
+                unsigned int u = (unsigned)b[4 * w] | ((unsigned)b[4 * w + 1] << 8) | ((unsigned)b[4 * w + 2] << 16) | ((unsigned)b[4 * w + 3] << 24);
+                reinterpret_cast<unsigned int*>(dst)[w] = u;
+            }
+        }
+    }
+}
+
 inline unsigned grid_for(int64_t total, int per_block = 256, int64_t cap = 16384) {
     int64_t nb = (total + per_block - 1) / per_block;
     if (nb > cap) nb = cap;
@@ -296,5 +325,24 @@ extern "C" int yume_vae_unpack_output(const void* x, int64_t ldx, int64_t T, int
     hipLaunchKernelGGL(unpack_output_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const unsigned short*)x,
                        ldx, (int)T, (int)H, (int)W, (int)Cv, ps, sub, mul, lo, hi, out);
     YUME_CHECK_LAUNCH("vae_unpack_output");
+    return YUME_OK;
+}
+
+extern "C" int yume_frames_u8(const float* video, int64_t C, int64_t T, int64_t H, int64_t W, void* out, void* stream) {
+    YUME_REQUIRE(video && out, "frames_u8: NULL pointer");
+    YUME_REQUIRE(C >= 1 && C <= 4 && T > 0 && H > 0 && W > 0, "frames_u8: bad shape C=%lld T=%lld H=%lld W=%lld", (long long)C, (long long)T, (long long)H, (long long)W);
+    const int64_t plane = T * H * W;
+    YUME_REQUIRE((plane % 4) == 0, "frames_u8: T*H*W=%lld must be a multiple of 4", (long long)plane);
+    YUME_REQUIRE(((uintptr_t)video % 16) == 0 && ((uintptr_t)out % 4) == 0, "frames_u8: pointer alignment");
+    const int64_t nquad = plane / 4;
+    hipStream_t st = (hipStream_t)stream;
+    unsigned char* o = (unsigned char*)out;
+    switch ((int)C) {
+        case 1: hipLaunchKernelGGL((frames_u8_kernel<1>), dim3(grid_for(nquad)), dim3(256), 0, st, video, plane, nquad, o); break;
+        case 2: hipLaunchKernelGGL((frames_u8_kernel<2>), dim3(grid_for(nquad)), dim3(256), 0, st, video, plane, nquad, o); break;
+        case 3: hipLaunchKernelGGL((frames_u8_kernel<3>), dim3(grid_for(nquad)), dim3(256), 0, st, video, plane, nquad, o); break;
+        default: hipLaunchKernelGGL((frames_u8_kernel<4>), dim3(grid_for(nquad)), dim3(256), 0, st, video, plane, nquad, o); break;
+    }
+    YUME_CHECK_LAUNCH("frames_u8");
     return YUME_OK;
 }
