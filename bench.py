@@ -196,6 +196,9 @@ def main():
     ap.add_argument("--layers", type=int, default=0, help="debug only: override num_layers (result is then NOT the named config)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-vae", action="store_true", help="skip the (untimed-in-value) VAE decode measurement")
+    ap.add_argument("--sp", action="store_true",
+                    help="5b only, not the headline: ONE chain split over the N ranks (Ulysses sequence parallelism, "
+                         "SURVEY 8(f).2); value is that chain's steps/s, scaling 'strong'")
     ap.add_argument("--workload", default="5b", choices=["5b", "14b"],
                     help="5b = BASELINE configs[1] (the headline metric, default); 14b = configs[2] (Yume-I2V-14B-540P, 65-frame clip, CFG)")
     args = ap.parse_args()
@@ -233,7 +236,10 @@ def main():
     plan = framepack.pack_plan(F, H, W, lfz)
     L = plan.seq_len
 
-    g = torch.Generator(device=dev).manual_seed(1000 + rank)          # each rank: its own prompt / noise
+    sp = bool(args.sp) and world > 1
+    if sp:
+        model.enable_sequence_parallel()                                 # all ranks: the same chain
+    g = torch.Generator(device=dev).manual_seed(1000 + (0 if sp else rank))   # each rank: its own prompt / noise
     hist = torch.randn((48, F - lfz, H, W), generator=g, device=dev)
     latent = torch.cat([hist, torch.randn((48, lfz, H, W), generator=g, device=dev)], dim=1)
     context = [torch.randn((77, 4096), generator=g, device=dev)]
@@ -299,12 +305,13 @@ def main():
         ms_per_step = tmax / args.steps * 1e3
         out = {
             "metric": "denoise-steps/sec (Yume-5B 720P, 33-frame latent)",
-            "value": world * args.steps / tmax, "unit": "denoise-steps/sec",
+            "value": (1 if sp else world) * args.steps / tmax, "unit": "denoise-steps/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "higher_is_better": True, "scaling": "strong" if sp else "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": "Yume-5B-720P random-init, 33-frame 704x1280 clip (latent 48x13x44x80, FramePack "
                                    "lfz=8, L=9460), ODE Euler steps of a 50-step shift-7 schedule, no CFG, one chain per GPU",
-                       "num_layers": cfg["num_layers"], "tokens": L, "parallelism": f"dp{world} (independent chains, replicated weights)"},
+                       "num_layers": cfg["num_layers"], "tokens": L, "parallelism": (f"sp{world} (one chain, Ulysses all-to-all, replicated weights)" if sp
+                                       else f"dp{world} (independent chains, replicated weights)")},
             "chain_checksums": checks, "weight_broadcast_collectives": n_bcast,
             "vae_decode": vae_res,
             "cached_context_ms_per_step": cached_ms,

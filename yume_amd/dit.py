@@ -42,6 +42,8 @@ class DiTEngine:
         # conditioning, not on the latent or the timestep; with cache_context they are computed once per conditioning
         # tensor (same object, same version) instead of once per denoise step. Off by default = the reference's work.
         self.cache_context = False
+        # a yume_amd.ulysses.SequenceParallel splits ONE chain's tokens over the ranks of its group
+        self.sp = None
         self._ctx_key = None
         self._ctx_refs = None
 
@@ -228,8 +230,9 @@ class DiTEngine:
             ops.rmsnorm_rope(kc, C, 1, nk_w, eps)
         ops.attn_fwd(hc, kc, vct, ac, L, nk, H, accumulate=accumulate)
 
-    def _blocks(self, xs, L, tab, row_idx, R, rope, n_rope, ctx, n_img, ctx_fresh=True):
-        """xs fp32 [L, C] in/out. tab fp32 [nb, R, 6, C]; rope fp32 [n_rope, 64, 2] (n_rope == L here)."""
+    def _blocks(self, xs, L, tab, row_idx, R, rope, n_rope, ctx, n_img, ctx_fresh=True, n_keys=None):
+        """xs fp32 [L, C] in/out. tab fp32 [nb, R, 6, C]; rope fp32 [n_rope, 64, 2] (n_rope == L here).
+        With sequence parallelism L is this rank's (padded) chunk and n_keys the true global token count."""
         m = self.model
         C, H, Fd, eps = m.dim, m.num_heads, m.ffn_dim, m.eps
         Lp = _round_up(L, 8)
@@ -251,8 +254,15 @@ class DiTEngine:
             else:
                 ops.rmsnorm_rope(qk[:n_rope], C, 2, d["nqk"], eps, rope)
                 ops.rmsnorm_rope(qk[n_rope:], C, 2, d["nqk"], eps, None)
-            ops.attn_fwd(qk[:, :C], qk[:, C:], vt, att, L, L, H)
-            ops.gemm_bf16(att, d["wo"], d["bo"], xs, EPI_RESID, gate=gate_sa, gate_stride=ts, row_idx=row_idx)
+            if self.sp is None:
+                ops.attn_fwd(qk[:, :C], qk[:, C:], vt, att, L, L, H)
+                sa = att
+            else:      # Ulysses: all tokens x this rank's heads, then back (2 collectives, yume_amd/ulysses.py)
+                qf, kf, vtf = self.sp.exchange_qkv(qk, vt, C)
+                of = self._buf("att_sp", (qf.shape[0], qf.shape[1]), torch.bfloat16)
+                ops.attn_fwd(qf, kf, vtf, of, qf.shape[0], n_keys, H // self.sp.world)
+                sa = self.sp.exchange_out(of)
+            ops.gemm_bf16(sa, d["wo"], d["bo"], xs, EPI_RESID, gate=gate_sa, gate_stride=ts, row_idx=row_idx)
             # --- cross attention
             if "n3w" in d:
                 ops.adaln_modulate(xs, d["n3w"], d["n3b"], 0, None, False, h, 0, eps)
@@ -278,6 +288,17 @@ class DiTEngine:
 
     def _head(self, xs_new, row_idx_new, e, R, grid):
         """xs_new fp32 [Ln, C] -> fp32 [Cout, F, 2*Hp, 2*Wp]."""
+        return self._unpatchify(self._head_rows(xs_new, row_idx_new, e, R), grid)
+
+    def _unpatchify(self, y, grid):
+        Co = self.model.out_dim
+        Fr, Hp, Wp = grid
+        out = torch.empty((Co, Fr, 2 * Hp, 2 * Wp), dtype=torch.float32, device=self.dev)
+        ops.unpatchify(y, Fr, Hp, Wp, 2, 2, Co, out)
+        return out
+
+    def _head_rows(self, xs_new, row_idx_new, e, R):
+        """xs_new fp32 [Ln, C] -> head output rows fp32 [Ln, 4*Cout] (model.py:344-347)."""
         m = self.model
         C, Co = m.dim, m.out_dim
         Ln = xs_new.shape[0]
@@ -288,10 +309,7 @@ class DiTEngine:
         ops.adaln_modulate(xs_new, th[1], th[0], C, row_idx_new, True, a3, 2, m.eps)
         y = self._buf("head_y", (Ln, 4 * Co), torch.float32)
         ops.gemm_bf16(a3, self.P["whead"], self.P["bhead"], y, EPI_F32)
-        Fr, Hp, Wp = grid
-        out = torch.empty((Co, Fr, 2 * Hp, 2 * Wp), dtype=torch.float32, device=self.dev)
-        ops.unpatchify(y, Fr, Hp, Wp, 2, 2, Co, out)
-        return out
+        return y
 
     # ------------------------------------------------------------------ one sample forward
     @torch.no_grad()
@@ -385,6 +403,30 @@ class DiTEngine:
                 self._img_ctx(clip_fea, ctx[:n_img])
             self._text_ctx(context, ctx[n_img:])
 
+        if self.sp is not None:
+            return self._forward_sp(xs, L, n_hist, tab.view(nb, R, 6, C), row_idx, R, rope, ctx, n_img, ctx_fresh, e, grid)
         self._blocks(xs, L, tab.view(nb, R, 6, C), row_idx, R, rope, L, ctx, n_img, ctx_fresh)
         ridx_new = row_idx[n_hist:] if row_idx is not None else None
         return self._head(xs[n_hist:], ridx_new, e, R, grid)
+
+    def _forward_sp(self, xs, L, n_hist, tab, row_idx, R, rope, ctx, n_img, ctx_fresh, e, grid):
+        """Blocks + head on this rank's token chunk (sequence_parallel.py:121-152: chunk after the embeddings, gather
+        after the head). The embeddings above were computed for all L tokens on every rank (< 0.1 % of the FLOPs)."""
+        sp, C = self.sp, self.model.dim
+        sp.check_heads(self.model.num_heads)
+        Lp, lo, hi = sp.chunk(L)
+        n = hi - lo
+        xl = self._buf("xs_sp", (Lp, C), torch.float32)
+        xl[:n].copy_(xs[lo:hi])
+        xl[n:].zero_()                                   # pad tokens: finite rows, masked as keys, dropped at the end
+        rl = self._buf("rope_sp", (Lp,) + tuple(rope.shape[1:]), torch.float32)
+        rl[:n].copy_(rope[lo:hi])
+        rl[n:].zero_()
+        il = None
+        if row_idx is not None:
+            il = self._buf("ridx_sp", (Lp,), torch.int32)
+            il[:n].copy_(row_idx[lo:hi])
+            il[n:].zero_()
+        self._blocks(xl, Lp, tab, il, R, rl, Lp, ctx, n_img, ctx_fresh, n_keys=L)
+        y = sp.gather_rows(self._head_rows(xl, il, e, R))
+        return self._unpatchify(y[n_hist:L].contiguous(), grid)

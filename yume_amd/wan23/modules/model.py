@@ -163,6 +163,14 @@ class WanModel(nn.Module):
             self._engine = DiTEngine(self, self._family)
         return self._engine
 
+    def enable_sequence_parallel(self, group=None):
+        """Split every following forward's tokens over the ranks of `group` (Ulysses all-to-all around the
+        self-attention; reference wan23/distributed/sequence_parallel.py:65-176). All ranks must call forward with the
+        same inputs and all receive the full output. `enable_sequence_parallel(False)` turns it off."""
+        from ...ulysses import SequenceParallel
+        self.engine.sp = None if group is False else SequenceParallel(group)
+        return self
+
     def forward(self, x, t, context, seq_len, enable_mask=False, y=None, latent_frame_zero=8, input_ids=None,
                 flag=True):
         """x: list of [C_in, F, H, W]; t: [1, seq_len] per-token (flag=True) or [B] / [B, seq_len]; context: list of
