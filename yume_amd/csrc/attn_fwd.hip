@@ -348,14 +348,30 @@ __device__ __forceinline__ void tile_body_v2(const char* kb, const AttnArgs& p, 
     const char* vb = kb + K_TILE_BYTES;
     f32x16 sacc[2];
 #pragma unroll
-    for (int b = 0; b < 2; ++b) {
+    for (int b = 0; b < 2; ++b)
 #pragma unroll
         for (int r = 0; r < 16; ++r) sacc[b][r] = 0.f;
+    {
+        // both 32-key halves per k-step, K fragments two k-steps ahead (3-deep ring, order pinned)
+        // row 32b + ql has the same swizzle as row ql: one per-lane offset per k-step + an immediate
+        bf16x8_t ka[3], kc[3];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            ka[ks] = *reinterpret_cast<const bf16x8_t*>(kb + koff[ks]);
+            kc[ks] = *reinterpret_cast<const bf16x8_t*>(kb + koff[ks] + 32 * 256);
+        }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) {
-            // row 32b + ql has the same swizzle as row ql: one per-lane offset per k-step + an immediate
-            const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(kb + koff[ks] + b * (32 * 256));
-            sacc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sacc[b], 0, 0, 0);
+            if (ks + 2 < 8) {
+                ka[(ks + 2) % 3] = *reinterpret_cast<const bf16x8_t*>(kb + koff[ks + 2]);
+                kc[(ks + 2) % 3] = *reinterpret_cast<const bf16x8_t*>(kb + koff[ks + 2] + 32 * 256);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            sacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka[ks % 3], qf[ks], sacc[0], 0, 0, 0);
+            sacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kc[ks % 3], qf[ks], sacc[1], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
     // rows >= Lk of the K tile are clamped copies of key Lk-1, so the row max needs no mask; their P is zeroed below
@@ -408,14 +424,23 @@ __device__ __forceinline__ void tile_body_v2(const char* kb, const AttnArgs& p, 
             pf[2 * b + e] = __builtin_bit_cast(bf16x8_t, w);
         }
 
-    // ---- O^T += V^T . P^T ---- (an explicit one-d-block-ahead fragment prefetch was measured: no gain, dropped)
+    // ---- O^T += V^T . P^T ----
+    // The S accumulators are dead once P is packed: their registers hold a 4-deep ring of V^T fragments, pinned with
+    // sched_barriers (left alone, the scheduler emits `ds_read ; s_waitcnt lgkmcnt(0) ; v_mfma` sixteen times).
+    // row 32db + ql swizzles like row ql ((d >> 1) & 7 is unchanged by + 32db)
+    __builtin_amdgcn_sched_barrier(0);
+    bf16x8_t vf[4];
 #pragma unroll
-    for (int db = 0; db < 4; ++db) {
+    for (int i = 0; i < 4; ++i) vf[i] = *reinterpret_cast<const bf16x8_t*>(vb + voff[i]);
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int sg = 0; sg < 4; ++sg) {
-            // row 32db + ql swizzles like row ql ((d >> 1) & 7 is unchanged by + 32db)
-            const bf16x8_t vf = *reinterpret_cast<const bf16x8_t*>(vb + voff[sg] + db * (32 * 128));
-            oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[sg], oacc[db], 0, 0, 0);
+    for (int i = 0; i < 16; ++i) {
+        const int db = i >> 2, sg = i & 3;
+        oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[sg], pf[sg], oacc[db], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (i + 4 < 16) {
+            vf[sg] = *reinterpret_cast<const bf16x8_t*>(vb + voff[sg] + (db + 1) * (32 * 128));
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
 }
