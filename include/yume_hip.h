@@ -119,6 +119,9 @@ int yume_rmsnorm_rope(void* buf, int64_t ld, int64_t T, int64_t C, int nparts,
  *     ldvt % 8 == 0 (the image written by YUME_EPI_BF16_SPLITT / yume_transpose_bf16).
  * O: bf16 token-major (ldo). accumulate != 0: O += result (the 14B image cross-attention sum,
  *    wan/modules/model.py:379-387) using the fp32 accumulator before rounding.
+ * variant: 0 = automatic (Lk >= 1536: 8-wave ping-pong kernel on whole rounds of 256-query workgroups + the 4-wave
+ *    kernel on the remaining query rows; otherwise the 4-wave kernel), 1 = 4-wave register-staged kernel,
+ *    2 = 4-wave LDS-DMA kernel, 4 = 8-wave ping-pong kernel. All compute the same function (tests compare them).
  */
 int yume_attn_fwd(const void* Q, int64_t ldq, const void* K, int64_t ldk, const void* Vt, int64_t ldvt,
                   void* O, int64_t ldo, int64_t Lq, int64_t Lk, int64_t H, float scale,

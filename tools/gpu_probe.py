@@ -71,7 +71,7 @@ def main():
         vtt = bf(Cc, (Lk + 7) // 8 * 8)
         o = torch.empty(Lq, Cc, dtype=torch.bfloat16, device=DEV)
         fl = 4 * Lq * Lk * Cc
-        for av in (1, 2):
+        for av in [int(v) for v in os.environ.get("YUME_ATTN_VARIANTS", "1,2,4").split(",")]:
             ms = timeit(lambda: ops.attn_fwd(q, k, vtt, o, Lq, Lk, Hh, variant=av), warm=1, iters=3)
             res[f"attn_{tag}_v{av}"] = {"ms": ms, "tflops": fl / ms / 1e9}
             print(f"attn {tag} v{av} Lq={Lq} Lk={Lk} H={Hh}: {ms:.3f} ms {fl/ms/1e9:.0f} TF", flush=True)

@@ -50,7 +50,8 @@ struct AttnArgs {
     int Lq, Lk, H;
     float scale_log2;  // softmax scale * log2(e)
     int accumulate;
-    int nqb;           // query blocks per head
+    int nqb;           // query blocks per head (of the rows [q_lo, Lq) this launch covers)
+    int q_lo;          // first query row of this launch
 };
 
 struct Stage {
@@ -131,7 +132,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(AttnArgs p) {
         h = xcd + 8 * (idx / p.nqb);
         qb = idx % p.nqb;
     }
-    const int q0 = qb * QB + wave * QW;
+    const int q0 = p.q_lo + qb * QB + wave * QW;
 
     // ---- Q^T fragments (B operand): lane (q = ql, hi) holds Q[q][16*ks + 8*hi .. +7] ----
     bf16x8_t qf[8];
@@ -462,7 +463,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel_v2(AttnArgs p) {
         h = xcd + 8 * (idx / p.nqb);
         qb = idx % p.nqb;
     }
-    const int q0 = qb * QB + wave * QW;
+    const int q0 = p.q_lo + qb * QB + wave * QW;
     bf16x8_t qf[8];
     {
         int q = q0 + ql;
@@ -547,6 +548,341 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel_v2(AttnArgs p) {
     }
 }
 
+
+// ---- v4: 8 waves, 256 queries per workgroup, one workgroup per CU, PING-PONG phases ------------------------------------
+// v2 keeps two independent 4-wave workgroups per CU; the two waves that share a SIMD run the same loop in phase, so they
+// fight for the matrix pipe during the S / PV products and leave it idle together during the softmax arithmetic
+// (measured MFMA utilisation 35 %). Here the loop is software-pipelined across key tiles into two phases
+//     X(t): O^T += V^T(t-1) . P^T(t-1)   then   S^T(t) = K(t) . Q^T        32 MFMAs, no exponentials
+//     Y(t): row max, rescale decision, exp2, row sum, pack P^T(t)           VALU only
+// separated by workgroup barriers, and waves 4..7 run ONE BARRIER BEHIND waves 0..3 (an extra barrier at their start, one
+// at the others' end): of the two waves on a SIMD (w and w + 4) one is in X while the other is in Y. K and V^T tiles are
+// shared by all 8 waves (half the LDS-DMA traffic of two 4-wave workgroups) in 3 + 3 slots of 16 KiB: at the start of
+// X(t) every thread issues its share of K(t+2) and V^T(t+1); at the end of X(t) a counted vmcnt leaves only that group in
+// flight, so a tile has 1.5-2 tile times to land and a slot is rewritten only after both halves finished reading it
+// (K(t-1) and V^T(t-2) were last read by the lagging half in the interval before the leading half issues X(t)).
+// The ragged last tile also comes by LDS-DMA: K rows >= Lk are fetched from row Lk-1 (their P is masked to 0), V^T
+// chunks that would leave the row are fetched from its last chunk, and the thread that fetched a chunk zeroes its keys
+// >= Lk in LDS right after its own vmcnt wait, before the barrier that publishes the tile (0 * garbage must be 0).
+constexpr int NW4 = 8;
+constexpr int QB4 = QW * NW4;             // 256 queries per workgroup
+constexpr int SLOT = K_TILE_BYTES;        // 16 KiB; K slots 0..2, V^T slots 3..5
+constexpr int V4_LDS = 6 * SLOT;          // 96 KiB
+
+struct Dma4 {
+    const char* kbase;      // K + h*D                         (uniform; tile t adds t*KT rows)
+    const char* vbase;      // V^T + h*D rows                  (uniform; tile t adds t*KT columns)
+    unsigned koff, voff;    // per-lane byte offsets of round 0
+    int64_t krow;           // bytes per K row
+    int64_t vrr;            // bytes between the two V^T rounds (64 rows)
+    int kr;                 // K row of this lane in round 0 (round 1: + 32)
+    int vc;                 // logical V^T chunk (8 keys) of this lane
+};
+
+__device__ __forceinline__ void dma4_init(Dma4& d, const AttnArgs& p, int h, int tid) {
+    d.kr = tid >> 4;
+    d.krow = p.ldk * 2;
+    d.kbase = reinterpret_cast<const char*>(p.K + h * D);
+    d.koff = (unsigned)(d.kr * d.krow) + (((tid & 15) ^ (d.kr & 15)) << 4);
+    const int dd = tid >> 3;
+    d.vc = (tid & 7) ^ ((dd >> 1) & 7);
+    d.vbase = reinterpret_cast<const char*>(p.Vt + (int64_t)h * D * p.ldvt);
+    d.voff = (unsigned)(dd * p.ldvt * 2) + (d.vc << 4);
+    d.vrr = 64 * p.ldvt * 2;
+}
+
+__device__ __forceinline__ void dma4_k(const Dma4& d, const AttnArgs& p, int t, bool last_ragged, char* slot, int tid) {
+    const char* base = d.kbase + (int64_t)t * KT * d.krow;
+    char* l = slot + (tid >> 6) * 1024;
+    if (!last_ragged) {
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr)
+            __builtin_amdgcn_global_load_lds((gbl_cvoid_t*)(base + rr * 32 * d.krow + d.koff), (lds_void_t*)(l + rr * 8192), 16, 0, 0);
+    } else {
+        const int nrow = p.Lk - t * KT;       // 1..63 valid rows
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {
+            const int r = d.kr + 32 * rr;
+            const int rc = r < nrow ? r : nrow - 1;
+            const char* g = base + (int64_t)rc * d.krow + (((tid & 15) ^ (d.kr & 15)) << 4);
+            __builtin_amdgcn_global_load_lds((gbl_cvoid_t*)g, (lds_void_t*)(l + rr * 8192), 16, 0, 0);
+        }
+    }
+}
+
+__device__ __forceinline__ void dma4_v(const Dma4& d, const AttnArgs& p, int t, bool last_ragged, char* slot, int tid) {
+    const char* base = d.vbase + (int64_t)t * KT * 2;
+    char* l = slot + (tid >> 6) * 1024;
+    unsigned off = d.voff;
+    if (last_ragged) {
+        const int kc = t * KT + d.vc * 8;                         // first key of this lane's chunk
+        const int kmax = (int)p.ldvt - 8;
+        if (kc > kmax) off -= (unsigned)((kc - kmax) * 2);         // stay inside the row; such a chunk is zeroed afterwards
+    }
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr)
+        __builtin_amdgcn_global_load_lds((gbl_cvoid_t*)(base + rr * d.vrr + off), (lds_void_t*)(l + rr * 8192), 16, 0, 0);
+}
+
+// keys >= Lk of the ragged last V^T tile -> 0, by the thread whose LDS-DMA brought the chunk (after its own vmcnt wait)
+__device__ __forceinline__ void fix4_v(const Dma4& d, const AttnArgs& p, int t, char* slot, int tid) {
+    const int nvalid = p.Lk - (t * KT + d.vc * 8);
+    if (nvalid >= 8) return;
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) {
+        u32x4* c = reinterpret_cast<u32x4*>(slot + rr * 8192 + tid * 16);
+        u32x4 x = *c;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            if (2 * w >= nvalid) x[w] = 0u;
+            else if (2 * w + 1 >= nvalid) x[w] &= 0xffffu;
+        }
+        *c = x;
+    }
+}
+
+template <bool MASK>
+__device__ __forceinline__ void softmax4(f32x16 (&sacc)[2], bf16x8_t (&pf)[4], f32x16 (&oacc)[4], float& m_run, float& l_run,
+                                         const AttnArgs& p, int j0, int hi) {
+    float mx = sacc[0][0];
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[b][r]);
+    mx = xhalf_max(mx);
+    const float m_new = fmaxf(m_run, mx * p.scale_log2);
+    if (!__all(m_new - m_run <= DEFER_LOG2)) {
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+        m_run = m_new;
+        l_run *= alpha;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
+    }
+    float ps0 = 0.f, ps1 = 0.f;
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float pv = __builtin_amdgcn_exp2f(fmaf(sacc[b][r], p.scale_log2, -m_run));
+            if (MASK) {
+                const int key = j0 + 32 * b + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                pv = key < p.Lk ? pv : 0.f;
+            }
+            sacc[b][r] = pv;
+            if (r & 1) ps1 += pv; else ps0 += pv;
+        }
+    l_run += ps0 + ps1;
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            u32x4 w;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const unsigned ev = pack_bf16x2(sacc[b][8 * e + 2 * i], sacc[b][8 * e + 2 * i + 1]);
+                const unsigned od = pack_bf16x2(sacc[b][8 * e + 4 + 2 * i], sacc[b][8 * e + 4 + 2 * i + 1]);
+                const auto r = __builtin_amdgcn_permlane32_swap(ev, od, false, false);
+                w[i] = r[0];
+                w[2 + i] = r[1];
+            }
+            pf[2 * b + e] = __builtin_bit_cast(bf16x8_t, w);
+        }
+}
+
+// fragment rings of the X phase: VD V^T fragments / KD K fragment pairs in flight (the S accumulators are dead during
+// the O^T products and the P fragments during S, so the registers are there; LDS latency under four reading waves is
+// several MFMA times)
+constexpr int VD = 4, KD = 3;   // deeper (8 / 4) measured 5 % slower
+__device__ __forceinline__ void pv4(const char* vb, const bf16x8_t (&pf)[4], f32x16 (&oacc)[4], const int (&voff)[4]) {
+    // product i: d-block db = i & 3, key group sg = i >> 2 — consecutive MFMAs write different accumulators
+    __builtin_amdgcn_sched_barrier(0);
+    bf16x8_t vf[VD];
+#pragma unroll
+    for (int i = 0; i < VD; ++i) vf[i] = *reinterpret_cast<const bf16x8_t*>(vb + voff[i >> 2] + (i & 3) * (32 * 128));
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int db = i & 3, sg = i >> 2;
+        oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[i % VD], pf[sg], oacc[db], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (i + VD < 16) {
+            const int n = i + VD;
+            vf[i % VD] = *reinterpret_cast<const bf16x8_t*>(vb + voff[n >> 2] + (n & 3) * (32 * 128));
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
+__device__ __forceinline__ void s4(const char* kb, const bf16x8_t (&qf)[8], f32x16 (&sacc)[2], const int (&koff)[8]) {
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sacc[b][r] = 0.f;
+    bf16x8_t ka[KD], kc[KD];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int ks = 0; ks < KD - 1; ++ks) {
+        ka[ks] = *reinterpret_cast<const bf16x8_t*>(kb + koff[ks]);
+        kc[ks] = *reinterpret_cast<const bf16x8_t*>(kb + koff[ks] + 32 * 256);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+        if (ks + KD - 1 < 8) {
+            ka[(ks + KD - 1) % KD] = *reinterpret_cast<const bf16x8_t*>(kb + koff[ks + KD - 1]);
+            kc[(ks + KD - 1) % KD] = *reinterpret_cast<const bf16x8_t*>(kb + koff[ks + KD - 1] + 32 * 256);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        sacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka[ks % KD], qf[ks], sacc[0], 0, 0, 0);
+        sacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kc[ks % KD], qf[ks], sacc[1], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+#define YUME_A4_BARRIER()                                  \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     \
+    __builtin_amdgcn_s_barrier();                          \
+    __builtin_amdgcn_sched_barrier(0)
+
+// steady-state tile: tile t (K slot KS = t % 3) with 1 <= t, t + 2 < number of full tiles — no ragged tile involved, both
+// DMA groups present, every LDS slot address a compile-time constant
+template <int KS>
+__device__ __forceinline__ void steady4(const Dma4& dp, const AttnArgs& p, int t, char* smem, int tid, const bf16x8_t (&qf)[8],
+                                        f32x16 (&sacc)[2], bf16x8_t (&pf)[4], f32x16 (&oacc)[4], float& m_run, float& l_run,
+                                        int hi, const int (&koff)[8], const int (&voff)[4]) {
+    dma4_k(dp, p, t + 2, false, smem + ((KS + 2) % 3) * SLOT, tid);
+    dma4_v(dp, p, t + 1, false, smem + (3 + (KS + 1) % 3) * SLOT, tid);
+    __builtin_amdgcn_s_setprio(1);
+    pv4(smem + (3 + (KS + 2) % 3) * SLOT, pf, oacc, voff);
+    s4(smem + KS * SLOT, qf, sacc, koff);
+    __builtin_amdgcn_s_setprio(0);
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");     // everything older than this phase's 4 LDS-DMAs has landed
+    YUME_A4_BARRIER();
+    softmax4<false>(sacc, pf, oacc, m_run, l_run, p, t * KT, hi);
+    YUME_A4_BARRIER();
+}
+
+// any tile: first, last, ragged, short groups (runtime slots)
+__device__ __forceinline__ void general4(const Dma4& dp, const AttnArgs& p, int t, int nt, bool ragged, char* smem, int tid,
+                                         const bf16x8_t (&qf)[8], f32x16 (&sacc)[2], bf16x8_t (&pf)[4], f32x16 (&oacc)[4],
+                                         float& m_run, float& l_run, int hi, const int (&koff)[8], const int (&voff)[4]) {
+    const int last = nt - 1;
+    const bool has_k = t + 2 < nt, has_v = t + 1 < nt;
+    if (has_k) dma4_k(dp, p, t + 2, ragged && t + 2 == last, smem + ((t + 2) % 3) * SLOT, tid);
+    if (has_v) dma4_v(dp, p, t + 1, ragged && t + 1 == last, smem + (3 + (t + 1) % 3) * SLOT, tid);
+    if (t > 0) pv4(smem + (3 + (t - 1) % 3) * SLOT, pf, oacc, voff);
+    s4(smem + (t % 3) * SLOT, qf, sacc, koff);
+    if (has_k) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if (has_v) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (ragged && t == last && nt > 1) fix4_v(dp, p, last, smem + (3 + last % 3) * SLOT, tid);
+    YUME_A4_BARRIER();
+    if (ragged && t == last)
+        softmax4<true>(sacc, pf, oacc, m_run, l_run, p, t * KT, hi);
+    else
+        softmax4<false>(sacc, pf, oacc, m_run, l_run, p, t * KT, hi);
+    YUME_A4_BARRIER();
+}
+
+__global__ __launch_bounds__(NW4 * 64, 2) void attn_fwd_kernel_v4(AttnArgs p) {
+    __shared__ __attribute__((aligned(16))) char smem[V4_LDS];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2;                 // 0: leading half, 1: the half that runs one barrier behind
+    const int hi = lane >> 5;
+    const int ql = lane & 31;
+    int h, qb;
+    {
+        const int bid = blockIdx.x;
+        const int xcd = bid & 7, idx = bid >> 3;
+        const int hx = (p.H + 7 - xcd) >> 3;
+        const int per = hx * p.nqb;
+        if (idx >= per) return;
+        h = xcd + 8 * (idx / p.nqb);
+        qb = idx % p.nqb;
+    }
+    const int q0 = p.q_lo + qb * QB4 + wave * QW;
+    bf16x8_t qf[8];
+    {
+        int q = q0 + ql;
+        q = q < p.Lq ? q : p.Lq - 1;
+        const unsigned short* qp = p.Q + (int64_t)q * p.ldq + h * D + 8 * hi;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) qf[ks] = *reinterpret_cast<const bf16x8_t*>(qp + 16 * ks);
+    }
+    f32x16 oacc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[i][r] = 0.f;
+    float m_run = NEG_BIG, l_run = 0.f;
+    int koff[8], voff[4];
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) koff[ks] = ql * 256 + (((2 * ks + hi) ^ (ql & 15)) << 4);
+#pragma unroll
+    for (int sg = 0; sg < 4; ++sg) voff[sg] = ql * 128 + (((2 * sg + hi) ^ ((ql >> 1) & 7)) << 4);
+    Dma4 dp;
+    dma4_init(dp, p, h, tid);
+
+    const int nt = (p.Lk + KT - 1) / KT;
+    const bool ragged = (p.Lk % KT) != 0;
+    const int nfull = ragged ? nt - 1 : nt;
+    const int last = nt - 1;
+    // ---- prologue: K(0), K(1), V^T(0) ----
+    dma4_k(dp, p, 0, ragged && last == 0, smem, tid);
+    if (nt > 1) dma4_k(dp, p, 1, ragged && last == 1, smem + SLOT, tid);
+    dma4_v(dp, p, 0, ragged && last == 0, smem + 3 * SLOT, tid);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (ragged && last == 0) fix4_v(dp, p, 0, smem + 3 * SLOT, tid);
+    YUME_A4_BARRIER();
+    if (grp == 1) { __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); }
+
+    f32x16 sacc[2];
+    bf16x8_t pf[4];
+    general4(dp, p, 0, nt, ragged, smem, tid, qf, sacc, pf, oacc, m_run, l_run, hi, koff, voff);
+    int t = 1;
+#pragma unroll 1
+    for (; t + 4 < nfull; t += 3) {            // t % 3 == 1 here; the three calls issue tiles up to t + 4 (all full tiles)
+        steady4<1>(dp, p, t, smem, tid, qf, sacc, pf, oacc, m_run, l_run, hi, koff, voff);
+        steady4<2>(dp, p, t + 1, smem, tid, qf, sacc, pf, oacc, m_run, l_run, hi, koff, voff);
+        steady4<0>(dp, p, t + 2, smem, tid, qf, sacc, pf, oacc, m_run, l_run, hi, koff, voff);
+    }
+#pragma unroll 1
+    for (; t < nt; ++t) general4(dp, p, t, nt, ragged, smem, tid, qf, sacc, pf, oacc, m_run, l_run, hi, koff, voff);
+    // ================= X(nt): the last tile's O^T products =================
+    pv4(smem + (3 + last % 3) * SLOT, pf, oacc, voff);
+    if (grp == 0) __builtin_amdgcn_s_barrier();
+
+    const float l_tot = xhalf_sum(l_run);
+    const float inv = 1.0f / l_tot;
+    const int q = q0 + ql;
+    if (q < p.Lq) {
+        unsigned short* op = p.O + (int64_t)q * p.ldo + h * D + 4 * hi;
+#pragma unroll
+        for (int db = 0; db < 4; ++db)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float v0 = oacc[db][4 * g + 0] * inv, v1 = oacc[db][4 * g + 1] * inv;
+                float v2 = oacc[db][4 * g + 2] * inv, v3 = oacc[db][4 * g + 3] * inv;
+                u32x2* dst = reinterpret_cast<u32x2*>(op + 32 * db + 8 * g);
+                if (p.accumulate) {
+                    const u32x2 old = *dst;
+                    v0 += bf16_to_f32((unsigned short)(old[0] & 0xffffu));
+                    v1 += bf16_to_f32((unsigned short)(old[0] >> 16));
+                    v2 += bf16_to_f32((unsigned short)(old[1] & 0xffffu));
+                    v3 += bf16_to_f32((unsigned short)(old[1] >> 16));
+                }
+                u32x2 o;
+                o[0] = pack_bf16x2(v0, v1);
+                o[1] = pack_bf16x2(v2, v3);
+                *dst = o;
+            }
+    }
+}
+
 }  // namespace
 
 
@@ -567,14 +903,43 @@ extern "C" int yume_attn_fwd(const void* Q, int64_t ldq, const void* K, int64_t 
     a.Lq = (int)Lq; a.Lk = (int)Lk; a.H = (int)H;
     a.scale_log2 = scale * 1.4426950408889634f;
     a.accumulate = accumulate;
-    a.nqb = (int)((Lq + QB - 1) / QB);
-    // every XCD slot gets ceil(H/8)*nqb block ids; surplus ids exit immediately
-    const int64_t per_xcd = ((H + 7) / 8) * a.nqb;
-    dim3 grid((unsigned)(per_xcd * 8)), block(NW * 64);
-    if (variant == 1)
-        hipLaunchKernelGGL(attn_fwd_kernel, grid, block, 0, (hipStream_t)stream, a);
-    else
-        hipLaunchKernelGGL(attn_fwd_kernel_v2, grid, block, 0, (hipStream_t)stream, a);
+    a.q_lo = 0;
+    a.nqb = 0;
+    hipStream_t st = (hipStream_t)stream;
+    // launch one kernel over the query rows [lo, hi)
+    auto run = [&](int kernel, int64_t lo, int64_t hi) {
+        AttnArgs b = a;
+        b.q_lo = (int)lo;
+        b.Lq = (int)hi;
+        const int qb = kernel == 4 ? QB4 : QB;
+        b.nqb = (int)((hi - lo + qb - 1) / qb);
+        // every XCD slot gets ceil(H/8)*nqb block ids; surplus ids exit immediately
+        const dim3 grid((unsigned)(((H + 7) / 8) * b.nqb * 8));
+        if (kernel == 4)
+            hipLaunchKernelGGL(attn_fwd_kernel_v4, grid, dim3(NW4 * 64), 0, st, b);
+        else if (kernel == 1)
+            hipLaunchKernelGGL(attn_fwd_kernel, grid, dim3(NW * 64), 0, st, b);
+        else
+            hipLaunchKernelGGL(attn_fwd_kernel_v2, grid, dim3(NW * 64), 0, st, b);
+    };
+    if (variant == 1 || variant == 2 || variant == 4) {
+        run(variant, 0, Lq);
+    } else if (Lk < 1536 || Lq < QB4) {
+        run(2, 0, Lq);           // few key tiles: the 4-wave kernel's shorter prologue / smaller blocks win (cross-attention)
+    } else {
+        // 8-wave ping-pong kernel, one 256-query workgroup per CU. When its last round of workgroups would fill at most
+        // ~60 % of an XCD's 32 CUs, cut the query range: whole rounds on the 8-wave kernel, the remaining rows as 128-query
+        // workgroups of the 4-wave kernel, which then run one per CU.
+        const int64_t hx = (H + 7) / 8, nq4 = (Lq + QB4 - 1) / QB4;
+        const int64_t nb = hx * nq4, R = nb / 32, r = nb % 32;
+        const int64_t nq_main = R >= 1 ? (32 * R) / hx : 0;
+        if (r > 0 && r <= 20 && nq_main >= 1 && nq_main < nq4) {
+            run(4, 0, nq_main * QB4);
+            run(2, nq_main * QB4, Lq);
+        } else {
+            run(4, 0, Lq);
+        }
+    }
     YUME_CHECK_LAUNCH("attn_fwd");
     return YUME_OK;
 }
