@@ -17,7 +17,6 @@
 // compute of the current tile) and double buffered in LDS: one barrier per key tile.
 // Roofline: MFMA (bf16 dense). Algorithmic work 4*Lq*Lk*128 flop per head.
 #include "common.hpp"
-#include <stdlib.h>
 
 namespace {
 
@@ -749,21 +748,19 @@ __device__ __forceinline__ void s4(const char* kb, const bf16x8_t (&qf)[8], f32x
 
 // steady-state tile: tile t (K slot KS = t % 3) with 1 <= t, t + 2 < number of full tiles — no ragged tile involved, both
 // DMA groups present, every LDS slot address a compile-time constant
-template <int KS, int DBG>
+template <int KS>
 __device__ __forceinline__ void steady4(const Dma4& dp, const AttnArgs& p, int t, char* smem, int tid, const bf16x8_t (&qf)[8],
                                         f32x16 (&sacc)[2], bf16x8_t (&pf)[4], f32x16 (&oacc)[4], float& m_run, float& l_run,
                                         int hi, const int (&koff)[8], const int (&voff)[4]) {
     dma4_k(dp, p, t + 2, false, smem + ((KS + 2) % 3) * SLOT, tid);
     dma4_v(dp, p, t + 1, false, smem + (3 + (KS + 1) % 3) * SLOT, tid);
     __builtin_amdgcn_s_setprio(1);
-    if (DBG != 2) {
-        pv4(smem + (3 + (KS + 2) % 3) * SLOT, pf, oacc, voff);
-        s4(smem + KS * SLOT, qf, sacc, koff);
-    }
+    pv4(smem + (3 + (KS + 2) % 3) * SLOT, pf, oacc, voff);
+    s4(smem + KS * SLOT, qf, sacc, koff);
     __builtin_amdgcn_s_setprio(0);
     asm volatile("s_waitcnt vmcnt(4)" ::: "memory");     // everything older than this phase's 4 LDS-DMAs has landed
     YUME_A4_BARRIER();
-    if (DBG != 1) softmax4<false>(sacc, pf, oacc, m_run, l_run, p, t * KT, hi);
+    softmax4<false>(sacc, pf, oacc, m_run, l_run, p, t * KT, hi);
     YUME_A4_BARRIER();
 }
 
@@ -789,7 +786,6 @@ __device__ __forceinline__ void general4(const Dma4& dp, const AttnArgs& p, int 
     YUME_A4_BARRIER();
 }
 
-template <int DBG>
 __global__ __launch_bounds__(NW4 * 64, 2) void attn_fwd_kernel_v4(AttnArgs p) {
     __shared__ __attribute__((aligned(16))) char smem[V4_LDS];
     const int tid = threadIdx.x;
@@ -850,9 +846,9 @@ __global__ __launch_bounds__(NW4 * 64, 2) void attn_fwd_kernel_v4(AttnArgs p) {
     int t = 1;
 #pragma unroll 1
     for (; t + 4 < nfull; t += 3) {            // t % 3 == 1 here; the three calls issue tiles up to t + 4 (all full tiles)
-        steady4<1, DBG>(dp, p, t, smem, tid, qf, sacc, pf, oacc, m_run, l_run, hi, koff, voff);
-        steady4<2, DBG>(dp, p, t + 1, smem, tid, qf, sacc, pf, oacc, m_run, l_run, hi, koff, voff);
-        steady4<0, DBG>(dp, p, t + 2, smem, tid, qf, sacc, pf, oacc, m_run, l_run, hi, koff, voff);
+        steady4<1>(dp, p, t, smem, tid, qf, sacc, pf, oacc, m_run, l_run, hi, koff, voff);
+        steady4<2>(dp, p, t + 1, smem, tid, qf, sacc, pf, oacc, m_run, l_run, hi, koff, voff);
+        steady4<0>(dp, p, t + 2, smem, tid, qf, sacc, pf, oacc, m_run, l_run, hi, koff, voff);
     }
 #pragma unroll 1
     for (; t < nt; ++t) general4(dp, p, t, nt, ragged, smem, tid, qf, sacc, pf, oacc, m_run, l_run, hi, koff, voff);
@@ -919,13 +915,8 @@ extern "C" int yume_attn_fwd(const void* Q, int64_t ldq, const void* K, int64_t 
         b.nqb = (int)((hi - lo + qb - 1) / qb);
         // every XCD slot gets ceil(H/8)*nqb block ids; surplus ids exit immediately
         const dim3 grid((unsigned)(((H + 7) / 8) * b.nqb * 8));
-        static const int dbg = getenv("YUME_ATTN_DBG") ? atoi(getenv("YUME_ATTN_DBG")) : 0;
-        if (kernel == 4 && dbg == 1)
-            hipLaunchKernelGGL(attn_fwd_kernel_v4<1>, grid, dim3(NW4 * 64), 0, st, b);
-        else if (kernel == 4 && dbg == 2)
-            hipLaunchKernelGGL(attn_fwd_kernel_v4<2>, grid, dim3(NW4 * 64), 0, st, b);
-        else if (kernel == 4)
-            hipLaunchKernelGGL(attn_fwd_kernel_v4<0>, grid, dim3(NW4 * 64), 0, st, b);
+        if (kernel == 4)
+            hipLaunchKernelGGL(attn_fwd_kernel_v4, grid, dim3(NW4 * 64), 0, st, b);
         else if (kernel == 1)
             hipLaunchKernelGGL(attn_fwd_kernel, grid, dim3(NW * 64), 0, st, b);
         else
