@@ -641,9 +641,54 @@ __device__ __forceinline__ void fix4_v(const Dma4& d, const AttnArgs& p, int t, 
     }
 }
 
+// exponentials + row sum + pack of one S tile against the exponent base m (S left untouched)
+template <bool MASK>
+__device__ __forceinline__ float exp_pack4(const f32x16 (&sacc)[2], bf16x8_t (&pf)[4], float m, const AttnArgs& p, int j0, int hi) {
+    typedef __attribute__((ext_vector_type(2))) float f32x2;
+    const f32x2 c2 = {p.scale_log2, p.scale_log2}, m2 = {-m, -m};
+    f32x2 ps = {0.f, 0.f};
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            float pv[8];
+#pragma unroll
+            for (int k = 0; k < 8; k += 2) {
+                const int r = 8 * e + k;
+                const f32x2 s2 = {sacc[b][r], sacc[b][r + 1]};
+                const f32x2 x2 = s2 * c2 + m2;                      // v_pk_fma_f32
+                f32x2 e2 = {__builtin_amdgcn_exp2f(x2[0]), __builtin_amdgcn_exp2f(x2[1])};
+                if (MASK) {
+                    const int key = j0 + 32 * b + (r & 3) + 8 * (r >> 2) + 4 * hi;   // r even: r + 1 is the next key
+                    e2[0] = key < p.Lk ? e2[0] : 0.f;
+                    e2[1] = key + 1 < p.Lk ? e2[1] : 0.f;
+                }
+                ps += e2;                                            // v_pk_add_f32
+                pv[k] = e2[0];
+                pv[k + 1] = e2[1];
+            }
+            u32x4 w;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const unsigned ev = pack_bf16x2(pv[2 * i], pv[2 * i + 1]);           // group 2e
+                const unsigned od = pack_bf16x2(pv[4 + 2 * i], pv[4 + 2 * i + 1]);   // group 2e+1
+                const auto r = __builtin_amdgcn_permlane32_swap(ev, od, false, false);
+                w[i] = r[0];
+                w[2 + i] = r[1];
+            }
+            pf[2 * b + e] = __builtin_bit_cast(bf16x8_t, w);
+        }
+    return ps[0] + ps[1];
+}
+
+// Online-softmax step with an OPTIMISTIC exponent base: the exponentials are issued against the running base m_run of
+// the previous tiles, so they do not wait for this tile's row-max reduction (a ~30-instruction dependent chain with a
+// cross-half swap and a wave vote); the reduction runs beside them and only decides whether the tile has to be redone
+// with a new base (some score exceeds the base by more than 2^8 — the first tile, then almost never). P <= 2^8 either way.
 template <bool MASK>
 __device__ __forceinline__ void softmax4(f32x16 (&sacc)[2], bf16x8_t (&pf)[4], f32x16 (&oacc)[4], float& m_run, float& l_run,
                                          const AttnArgs& p, int j0, int hi) {
+    float psum = exp_pack4<MASK>(sacc, pf, m_run, p, j0, hi);
     float mx = sacc[0][0];
 #pragma unroll
     for (int b = 0; b < 2; ++b)
@@ -659,36 +704,9 @@ __device__ __forceinline__ void softmax4(f32x16 (&sacc)[2], bf16x8_t (&pf)[4], f
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
+        psum = exp_pack4<MASK>(sacc, pf, m_run, p, j0, hi);
     }
-    float ps0 = 0.f, ps1 = 0.f;
-#pragma unroll
-    for (int b = 0; b < 2; ++b)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            float pv = __builtin_amdgcn_exp2f(fmaf(sacc[b][r], p.scale_log2, -m_run));
-            if (MASK) {
-                const int key = j0 + 32 * b + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                pv = key < p.Lk ? pv : 0.f;
-            }
-            sacc[b][r] = pv;
-            if (r & 1) ps1 += pv; else ps0 += pv;
-        }
-    l_run += ps0 + ps1;
-#pragma unroll
-    for (int b = 0; b < 2; ++b)
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            u32x4 w;
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const unsigned ev = pack_bf16x2(sacc[b][8 * e + 2 * i], sacc[b][8 * e + 2 * i + 1]);
-                const unsigned od = pack_bf16x2(sacc[b][8 * e + 4 + 2 * i], sacc[b][8 * e + 4 + 2 * i + 1]);
-                const auto r = __builtin_amdgcn_permlane32_swap(ev, od, false, false);
-                w[i] = r[0];
-                w[2 + i] = r[1];
-            }
-            pf[2 * b + e] = __builtin_bit_cast(bf16x8_t, w);
-        }
+    l_run += psum;
 }
 
 // fragment rings of the X phase: VD V^T fragments / KD K fragment pairs in flight (the S accumulators are dead during
