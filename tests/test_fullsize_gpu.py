@@ -169,3 +169,55 @@ def test_full_resolution_decoder_is_causal():
     assert full.shape == (3, 29, 704, 1280) and head.shape == (3, 9, 704, 1280)
     assert torch.isfinite(full).all() and full.abs().max() <= 1.0
     assert torch.equal(head, full[:, :9])
+
+
+def test_full_14b_engine_identity_blocks_vs_oracle():
+    """BASELINE configs[2] geometry (Yume-I2V-14B-540P, latent [16,17,68,120] + y, FramePack lfz=9, L = 27810, 40 blocks
+    of width 5120) with identity blocks: embeddings (x|y concat, pyramid, CLIP image tokens) + head against the oracle."""
+    from yume_amd import framepack
+    from yume_amd.wan.modules.model import WanModel
+    cfg = dict(synth.CFG_14B)
+    with torch.device(DEV):
+        model = WanModel(**cfg).attach_pyramid()
+    synth.randomize_module_(model, seed=5)
+    _identity_blocks_(model)
+    model = model.eval().requires_grad_(False)
+    F, H, W, lfz = 17, 68, 120, 9
+    L = framepack.pack_plan(F, H, W, lfz, F - 9).seq_len
+    assert L == 27810
+    g = torch.Generator().manual_seed(11)
+    x, y = torch.randn(16, F, H, W, generator=g), torch.randn(20, F, H, W, generator=g)
+    ctx, clip = torch.randn(77, 4096, generator=g), torch.randn(1, 257, 1280, generator=g)
+    t = torch.tensor([612.0])
+    got, cache = model([x.to(DEV)], t=t.to(DEV), context=[ctx.to(DEV)], seq_len=L, clip_fea=clip.to(DEV), y=[y.to(DEV)],
+                       rand_num_img=0.6, latent_frame_zero=lfz)
+    assert cache is None and got.shape == (16, lfz, H, W) and torch.isfinite(got).all()
+    sd = {k: v.detach().float().cpu() for k, v in model.state_dict().items() if not k.startswith("blocks.")}
+    want = odit.forward_wan(sd, dict(cfg, num_layers=0), x, t, ctx, L, clip[0], y, 0.6, lfz)
+    e = rel_l2(got.cpu(), want)
+    print(f"full 14B (configs[2] geometry), identity blocks: rel-L2 {e:.3e}")
+    assert e <= 5e-3
+
+
+def test_full_resolution_wan21_decoder_is_causal():
+    """Wan2.1 VAE at 544x960 (the 14B pipeline's decoder, vae.py:544-568): decode(z[:, :4]) == decode(z[:, :13])[:, :13]."""
+    from yume_amd.wan.modules.vae import WanVAE, WanVAE_
+    cfg = synth.VAE_CFG_21
+    with torch.device(DEV):
+        m = WanVAE_(dim=cfg["dim"], z_dim=cfg["z_dim"], temperal_downsample=cfg["temperal_downsample"])
+    g = torch.Generator(device=DEV).manual_seed(1)
+    with torch.no_grad():
+        for k, p in m.named_parameters():
+            if k.endswith("gamma"):
+                p.copy_(1 + 0.1 * torch.randn(p.shape, generator=g, device=DEV))
+            elif k.endswith("bias"):
+                p.copy_(0.02 * torch.randn(p.shape, generator=g, device=DEV))
+            else:
+                p.copy_((torch.rand(p.shape, generator=g, device=DEV) * 2 - 1) * (3.0 / p[0].numel()) ** 0.5)
+    vae = WanVAE(z_dim=cfg["z_dim"], device=DEV, model=m)
+    z = torch.randn(16, 13, 68, 120, device=DEV, generator=g)
+    full = vae.decode([z])[0]
+    head = vae.decode([z[:, :4].contiguous()])[0]
+    assert full.shape == (3, 49, 544, 960) and head.shape == (3, 13, 544, 960)
+    assert torch.isfinite(full).all() and full.abs().max() <= 1.0
+    assert torch.equal(head, full[:, :13])
