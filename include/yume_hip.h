@@ -87,7 +87,8 @@ enum {
     YUME_EPI_F32 = 2,
     YUME_EPI_RESID = 3,
     YUME_EPI_BF16_SPLITT = 4,
-    YUME_EPI_BF16_GELU_ERF = 5
+    YUME_EPI_BF16_GELU_ERF = 5,
+    YUME_EPI_BF16_GEGLU = 6      /* see the T5 section below */
 };
 int yume_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias,
                    int64_t M, int64_t N, int64_t K, int epi,
@@ -265,6 +266,26 @@ int yume_vae_unpack_output(const void* x, int64_t ldx, int64_t T, int64_t H, int
  * video: fp32 [C, T, H, W] (C <= 4, T*H*W % 4 == 0) -> out: uint8 [T, H, W, C]. Bit-exact (fp32, round half to even).
  */
 int yume_frames_u8(const float* video, int64_t C, int64_t T, int64_t H, int64_t W, void* out, void* stream);
+
+/* ======================================================================================================
+ * umT5-XXL text encoder (the step before the path; wan/modules/t5.py:440-513 T5EncoderModel,
+ * :262-291 T5Encoder, :143-178 T5SelfAttention). It runs on the DiT's GEMM kernels plus four small pieces:
+ *   yume_rmsnorm_f32       T5LayerNorm (t5.py:53-67): out bf16 = x * rsqrt(mean(x^2) + eps) * w, x fp32 [T, C]
+ *   YUME_EPI_BF16_GEGLU    T5FeedForward's fc1(x) * gelu_tanh(gate(x)) (t5.py:116-141) in ONE GEMM: W = the rows of gate
+ *                          and fc1 interleaved (row 2j = gate_j, row 2j+1 = fc1_j), N = 2*dim_ffn, out bf16 [M, N/2]
+ *   yume_gemm_bf16_batched the per-head q.k^T and P.v products (t5.py:105-109), `batch` launches per call
+ *   yume_softmax_bias_rows P[h,i,:n] = softmax_j(S[h,i,j] + bias[h, j-i+n-1]) (T5 does not scale; bias = the layer's
+ *                          relative-position embedding, t5.py:215-259), P[h,i,n:ldp] = 0
+ * Padding tokens are not computed at all: their keys are masked to exactly zero weight in the reference (finfo.min bias)
+ * and their rows are dropped by T5EncoderModel.__call__ (`u[:v]`), so running on the valid tokens only is identical.
+ */
+int yume_rmsnorm_f32(const float* x, int64_t ldx, int64_t T, int64_t C, float eps, const float* w, void* out, int64_t ldo,
+                     void* stream);
+int yume_gemm_bf16_batched(const void* A, int64_t lda, int64_t strideA, const void* W, int64_t ldw, int64_t strideW,
+                           int64_t M, int64_t N, int64_t K, int epi, void* out, int64_t ldo, int64_t strideO,
+                           int64_t batch, int variant, void* stream);
+int yume_softmax_bias_rows(const float* S, int64_t lds, int64_t strideS, int64_t H, int64_t n, const float* bias,
+                           int64_t ldb, void* P, int64_t ldp, int64_t strideP, void* stream);
 
 #ifdef __cplusplus
 }

@@ -107,3 +107,29 @@ def ref_vae(which="vae2_2"):
         spec.loader.exec_module(m)
         _cache[key] = m
     return _cache[key]
+
+
+def ref_t5():
+    """Returns the reference text-encoder module wan/modules/t5.py (its `.tokenizers` import — HuggingFace tokenizer glue with
+    ftfy/regex dependencies — is replaced by an empty stand-in: only the nn.Modules are used)."""
+    assert available(), "reference tree not present"
+    if "t5" not in _cache:
+        pkg = "yume_ref_t5pkg"
+        root = types.ModuleType(pkg)
+        root.__path__ = [os.path.join(REF_ROOT, "wan", "modules")]
+        tok = types.ModuleType(pkg + ".tokenizers")
+        tok.HuggingfaceTokenizer = type("HuggingfaceTokenizer", (), {})
+        sys.modules[pkg] = root
+        sys.modules[pkg + ".tokenizers"] = tok
+        spec = importlib.util.spec_from_file_location(pkg + ".t5", os.path.join(REF_ROOT, "wan", "modules", "t5.py"))
+        m = importlib.util.module_from_spec(spec)
+        sys.modules[pkg + ".t5"] = m
+        # t5.py:478 evaluates torch.cuda.current_device() as a default argument at import time: no GPU in this container
+        real = torch.cuda.current_device
+        torch.cuda.current_device = lambda: 0
+        try:
+            spec.loader.exec_module(m)
+        finally:
+            torch.cuda.current_device = real
+        _cache["t5"] = m
+    return _cache["t5"]

@@ -19,6 +19,9 @@ SIGNATURES = {
     "yume_target_arch": [],
     "yume_adaln_modulate": [_P, _L, _L, _L, _F, _P, _P, _L, _P, _I, _P, _L, _I, _P],
     "yume_gemm_bf16": [_P, _L, _P, _L, _P, _L, _L, _L, _I, _P, _L, _P, _L, _P, _P, _L, _L, _I, _P],
+    "yume_rmsnorm_f32": [_P, _L, _L, _L, _F, _P, _P, _L, _P],
+    "yume_gemm_bf16_batched": [_P, _L, _L, _P, _L, _L, _L, _L, _L, _I, _P, _L, _L, _L, _I, _P],
+    "yume_softmax_bias_rows": [_P, _L, _L, _L, _L, _P, _L, _P, _L, _L, _P],
     "yume_rmsnorm_rope": [_P, _L, _L, _L, _I, _P, _F, _P, _L, _P],
     "yume_attn_fwd": [_P, _L, _P, _L, _P, _L, _P, _L, _L, _L, _L, _F, _I, _I, _P],
     "yume_linear_smallm_f32": [_P, _L, _L, _P, _I, _P, _L, _I, _I, _P, _P, _P],

@@ -18,6 +18,7 @@ using namespace gemm_core;
 namespace {
 
 struct ConvA {
+    __device__ __forceinline__ void batch_offset(int) {}
     const unsigned short* x;       // [Tin, Hin, Win, ldc]
     const unsigned short* cache;   // [2, Hin, Win, ldc] or nullptr
     const unsigned short* zero;    // >= 16 bytes of zeros
@@ -89,6 +90,7 @@ struct ConvA {
 // validity-bit test, one compare and a 64-bit add: every row keeps the address of its tap-(0,0,0) source element and a
 // 27-bit mask of the spatially valid taps; frames before the chunk (ti < 0) are the same offset from the cache base.
 struct ConvAFast {
+    __device__ __forceinline__ void batch_offset(int) {}
     const unsigned short* x;
     const unsigned short* cache;
     const unsigned short* zero;
@@ -176,6 +178,7 @@ extern "C" int yume_conv3d_cl(const void* x, const void* cache, int64_t ldc, int
     p.tiles_m = (int)((M + BM - 1) / BM);
     p.tiles_n = (int)((Cout + BN - 1) / BN);
     p.group_m = 8;
+    p.bsW = 0; p.bsO = 0;
     ConvA al = {};
     al.x = (const unsigned short*)x; al.cache = (const unsigned short*)cache; al.zero = (const unsigned short*)zero_page;
     al.ldc = ldc;

@@ -22,8 +22,9 @@ extern "C" int yume_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t
     p.tiles_m = (int)((M + BM - 1) / BM);
     p.tiles_n = (int)((N + BN - 1) / BN);
     p.group_m = 8;
+    p.bsW = 0; p.bsO = 0;
     PlainA al;
-    al.A = (const unsigned short*)A; al.lda = lda; al.M = (int)M;
+    al.A = (const unsigned short*)A; al.lda = lda; al.M = (int)M; al.bsA = 0;
     Epilogue e = {};
     e.bias = bias;
     e.out = out; e.ldo = ldo;
@@ -40,6 +41,9 @@ extern "C" int yume_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t
         case YUME_EPI_RESID:
             YUME_REQUIRE(gate == nullptr || (gate_stride % 4) == 0, "gemm_bf16: gate_stride must be a multiple of 4");
             return YUME_GO(YUME_EPI_RESID);
+        case YUME_EPI_BF16_GEGLU:
+            YUME_REQUIRE((N % 8) == 0 && bias == nullptr, "gemm_bf16: GEGLU needs N %% 8 == 0 and no bias");
+            return launch256<YUME_EPI_BF16_GEGLU>(p, al, e, st, "gemm_bf16");     // 256x256 kernel only (vector epilogue)
         case YUME_EPI_BF16_SPLITT:
             YUME_REQUIRE(outT != nullptr && n_split >= 0 && (n_split % BN) == 0 && ldt >= M && (ldt % 4) == 0,
                          "gemm_bf16: SPLITT needs outT, n_split %% 128 == 0, ldt >= M and ldt %% 4 == 0");
@@ -49,4 +53,35 @@ extern "C" int yume_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t
             yume_set_error("gemm_bf16: unknown epilogue %d", epi);
             return YUME_EINVAL;
     }
+}
+
+// `batch` independent small GEMMs of one shape (the per-head score / value products of the T5 encoder's attention) in ONE
+// launch of the 128x128 kernel (gridDim.y = batch). Strides are in ELEMENTS of the respective tensor.
+extern "C" int yume_gemm_bf16_batched(const void* A, int64_t lda, int64_t strideA, const void* W, int64_t ldw, int64_t strideW,
+                                      int64_t M, int64_t N, int64_t K, int epi, void* out, int64_t ldo, int64_t strideO,
+                                      int64_t batch, int variant, void* stream) {
+    (void)variant;
+    YUME_REQUIRE(A && W && out, "gemm_bf16_batched: NULL pointer");
+    YUME_REQUIRE(epi == YUME_EPI_BF16 || epi == YUME_EPI_F32, "gemm_bf16_batched: only the plain bf16 / fp32 epilogues");
+    YUME_REQUIRE(batch >= 1 && batch <= 65535, "gemm_bf16_batched: batch %lld", (long long)batch);
+    YUME_REQUIRE(M > 0 && N > 0 && K > 0 && M < (1ll << 31) && N < (1ll << 31) && K < (1ll << 31), "gemm_bf16_batched: bad problem size");
+    YUME_REQUIRE((K % BK) == 0 && (N % 4) == 0, "gemm_bf16_batched: K must be a multiple of %d and N of 4", BK);
+    YUME_REQUIRE((lda % 8) == 0 && (ldw % 8) == 0 && (ldo % 4) == 0, "gemm_bf16_batched: lda/ldw must be multiples of 8, ldo of 4");
+    YUME_REQUIRE((strideA % 8) == 0 && (strideW % 8) == 0 && (strideO % 8) == 0, "gemm_bf16_batched: strides must keep 16-byte alignment");
+    YUME_REQUIRE(((uintptr_t)A % 16) == 0 && ((uintptr_t)W % 16) == 0 && ((uintptr_t)out % 16) == 0, "gemm_bf16_batched: pointers must be 16-byte aligned");
+    Problem p;
+    p.W = (const unsigned short*)W; p.ldw = ldw;
+    p.M = (int)M; p.N = (int)N; p.K = (int)K;
+    p.tiles_m = (int)((M + BM - 1) / BM);
+    p.tiles_n = (int)((N + BN - 1) / BN);
+    p.group_m = 8;
+    p.bsW = strideW;
+    p.bsO = strideO * (epi == YUME_EPI_F32 ? 4 : 2);
+    PlainA al;
+    al.A = (const unsigned short*)A; al.lda = lda; al.M = (int)M; al.bsA = strideA;
+    Epilogue e = {};
+    e.out = out; e.ldo = ldo;
+    hipStream_t st = (hipStream_t)stream;
+    if (epi == YUME_EPI_F32) return launch<YUME_EPI_F32>(p, al, e, st, "gemm_bf16_batched", (int)batch);
+    return launch<YUME_EPI_BF16>(p, al, e, st, "gemm_bf16_batched", (int)batch);
 }

@@ -27,7 +27,8 @@ constexpr int LDS_BYTES = 2 * STAGE_BYTES;       // double buffered = 64 KiB
 
 // internal epilogue ids beyond the public YUME_EPI_* (conv3d.hip)
 constexpr int EPI_BF16_ADD = 16;      // out bf16 = acc + bias + add[m, n]   (add bf16, ld = ldadd)
-constexpr int EPI_BF16_TSPLIT = 17;   // out bf16 row m=(t,hw), col n=(j,c) -> out[((2t+j)*HW + hw), c]   (time_conv interleave)
+constexpr int EPI_BF16_TSPLIT = 17;
+// public YUME_EPI_BF16_GEGLU = 6: W rows interleaved (gate_j, fc1_j): out bf16 [M, N/2], out[m, j] = acc[2j+1] * gelu_tanh(acc[2j])   // out bf16 row m=(t,hw), col n=(j,c) -> out[((2t+j)*HW + hw), c]   (time_conv interleave)
 
 struct Epilogue {
     const float* bias;
@@ -43,6 +44,7 @@ struct Problem {
     int M, N, K;
     int tiles_m, tiles_n;
     int group_m;   // 256^2 kernel: M-tiles per traversal group (L2 reuse knob)
+    int64_t bsW, bsO;   // batched launch (gridDim.y > 1, 128^2 kernel): W stride in elements, out stride in BYTES per batch index
 };
 
 typedef __attribute__((address_space(3))) void lds_void;
@@ -54,7 +56,9 @@ typedef __attribute__((address_space(1))) const void gbl_cvoid;
 // k-chunk (tid%8) ^ (row & 7) of K tile kt; advance() after each tile.
 struct PlainA {
     const unsigned short* A; int64_t lda; int M;
+    int64_t bsA;   // batched launch: A stride in elements per batch index
     const unsigned short* rowp[4];
+    __device__ __forceinline__ void batch_offset(int b) { A += (int64_t)b * bsA; }
     // kshift selects the LDS swizzle key of a row: (row >> kshift) & 7 (0 for the 16x16 fragments, 1 for 32x32 ones)
     __device__ __forceinline__ void init(int m0, int tid, int rpr = 32, int kshift = 0) {
 #pragma unroll
@@ -209,6 +213,11 @@ __global__ __launch_bounds__(NTHR, 2) void gemm128_kernel(Problem p, ALoad al, E
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
+    if (gridDim.y > 1) {          // batched launch: independent problems of one shape, operands a fixed stride apart
+        al.batch_offset(blockIdx.y);
+        p.W += (int64_t)blockIdx.y * p.bsW;
+        e.out = reinterpret_cast<char*>(e.out) + (int64_t)blockIdx.y * p.bsO;
+    }
 
     // ---- workgroup -> tile (XCD-aware, grouped) ----
     const int nwg = p.tiles_m * p.tiles_n;
@@ -338,6 +347,9 @@ __device__ __forceinline__ void store_row4(f32x4 v, int m, int n, const Problem&
     if (e.bias) v += *reinterpret_cast<const f32x4*>(e.bias + n);
     if (EPI == YUME_EPI_F32) {
         *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(e.out) + (int64_t)m * e.ldo + n) = v;
+    } else if (EPI == YUME_EPI_BF16_GEGLU) {
+        const unsigned o = pack_bf16x2(v[1] * gelu_tanh(v[0]), v[3] * gelu_tanh(v[2]));
+        *reinterpret_cast<unsigned*>(reinterpret_cast<unsigned short*>(e.out) + (int64_t)m * e.ldo + (n >> 1)) = o;
     } else if (EPI == YUME_EPI_RESID) {
         float* xo = reinterpret_cast<float*>(e.out) + (int64_t)m * e.ldo + n;
         f32x4 x = *reinterpret_cast<const f32x4*>(xo);
@@ -636,8 +648,8 @@ inline bool use_256(const Problem& p, int variant, bool split_ok) {
 }
 
 template <int EPI, class ALoad>
-int launch(const Problem& p, const ALoad& al, const Epilogue& e, hipStream_t st, const char* what) {
-    dim3 grid((unsigned)(p.tiles_m * p.tiles_n)), block(NTHR);
+int launch(const Problem& p, const ALoad& al, const Epilogue& e, hipStream_t st, const char* what, int batch = 1) {
+    dim3 grid((unsigned)(p.tiles_m * p.tiles_n), (unsigned)batch), block(NTHR);
     hipLaunchKernelGGL((gemm128_kernel<EPI, ALoad>), grid, block, 0, st, p, al, e);
     YUME_CHECK_LAUNCH(what);
     return YUME_OK;

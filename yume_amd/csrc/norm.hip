@@ -22,7 +22,8 @@ __device__ __forceinline__ float block_sum(float v, float* red /*[8]*/) {
 }
 
 // MAXV = max float4 vectors per thread (C <= NT*4*MAXV)
-template <int MAXV>
+// RMS = true: T5LayerNorm (wan/modules/t5.py:53-67): y = x * rsqrt(mean(x^2) + eps) * w — no mean subtraction, no shift
+template <int MAXV, bool RMS = false>
 __global__ __launch_bounds__(NT) void adaln_kernel(const float* __restrict__ x, int64_t ldx, int C, float eps,
                                                    const float* __restrict__ mul, const float* __restrict__ add,
                                                    int64_t tab_stride, const int32_t* __restrict__ row_idx,
@@ -44,7 +45,7 @@ __global__ __launch_bounds__(NT) void adaln_kernel(const float* __restrict__ x, 
             v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
     }
-    const float mean = block_sum(s, red) / (float)C;
+    const float mean = RMS ? 0.f : block_sum(s, red) / (float)C;
     float q = 0.f;
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
@@ -61,13 +62,13 @@ __global__ __launch_bounds__(NT) void adaln_kernel(const float* __restrict__ x, 
     const float rstd = rsqrtf(var + eps);
     const int64_t row = row_idx ? (int64_t)row_idx[t] : 0;
     const float* mr = mul + row * tab_stride;
-    const float* ar = add + row * tab_stride;
+    const float* ar = RMS ? mr : add + row * tab_stride;
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
         const int vi = threadIdx.x + i * NT;
         if (vi < nvec) {
             const f32x4 m4 = *reinterpret_cast<const f32x4*>(mr + 4 * vi);
-            const f32x4 a4 = *reinterpret_cast<const f32x4*>(ar + 4 * vi);
+            const f32x4 a4 = RMS ? f32x4{0.f, 0.f, 0.f, 0.f} : *reinterpret_cast<const f32x4*>(ar + 4 * vi);
             f32x4 y;
 #pragma unroll
             for (int j = 0; j < 4; ++j) y[j] = (v[i][j] - mean) * rstd * (m4[j] + add_one) + a4[j];
@@ -185,6 +186,24 @@ extern "C" int yume_adaln_modulate(const float* x, int64_t ldx, int64_t T, int64
     else
         hipLaunchKernelGGL(adaln_kernel<8>, grid, block, 0, st, x, ldx, (int)C, eps, mul, add, tab_stride, row_idx, one, out, ldo, out_kind);
     YUME_CHECK_LAUNCH("adaln_modulate");
+    return YUME_OK;
+}
+
+extern "C" int yume_rmsnorm_f32(const float* x, int64_t ldx, int64_t T, int64_t C, float eps, const float* w, void* out,
+                                int64_t ldo, void* stream) {
+    YUME_REQUIRE(x && w && out, "rmsnorm_f32: NULL pointer");
+    YUME_REQUIRE(T >= 0 && C > 0 && (C % 8) == 0 && C <= 8192, "rmsnorm_f32: C=%lld must be a multiple of 8 and <= 8192", (long long)C);
+    YUME_REQUIRE((ldx % 4) == 0 && (ldo % 4) == 0, "rmsnorm_f32: strides must be multiples of 4");
+    if (T == 0) return YUME_OK;
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid((unsigned)T), block(NT);
+    if (C <= NT * 4 * 3)
+        hipLaunchKernelGGL((adaln_kernel<3, true>), grid, block, 0, st, x, ldx, (int)C, eps, w, w, (int64_t)0, (const int32_t*)nullptr, 0.f, out, ldo, 0);
+    else if (C <= NT * 4 * 5)
+        hipLaunchKernelGGL((adaln_kernel<5, true>), grid, block, 0, st, x, ldx, (int)C, eps, w, w, (int64_t)0, (const int32_t*)nullptr, 0.f, out, ldo, 0);
+    else
+        hipLaunchKernelGGL((adaln_kernel<8, true>), grid, block, 0, st, x, ldx, (int)C, eps, w, w, (int64_t)0, (const int32_t*)nullptr, 0.f, out, ldo, 0);
+    YUME_CHECK_LAUNCH("rmsnorm_f32");
     return YUME_OK;
 }
 

@@ -233,6 +233,45 @@ __global__ __launch_bounds__(256) void frames_u8_kernel(const float* __restrict_
     }
 }
 
+// T5 attention rows (wan/modules/t5.py:95-112): P[h,i,:n] = softmax_j(S[h,i,j] + bias[h, j - i + n - 1]), no scaling;
+// one wave per row, n <= 1024; P[h,i,n:ldp] = 0 (the K padding of the following P.V product)
+__global__ __launch_bounds__(256) void softmax_bias_kernel(const float* __restrict__ S, int64_t lds, int64_t strideS, int n,
+                                                           const float* __restrict__ bias, int64_t ldb,
+                                                           unsigned short* __restrict__ P, int64_t ldp, int64_t strideP,
+                                                           int64_t rows_total) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows_total) return;
+    const int64_t h = row / n;
+    const int i = (int)(row - h * n);
+    const float* s = S + h * strideS + (int64_t)i * lds;
+    const float* b = bias + h * ldb + (n - 1 - i);
+    unsigned short* o = P + h * strideP + (int64_t)i * ldp;
+    float v[16];
+    float mx = -3.0e38f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int j = lane + 64 * k;
+        v[k] = j < n ? s[j] + b[j] : -3.0e38f;
+        mx = fmaxf(mx, v[k]);
+    }
+    mx = wave_max(mx);
+    float sum = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int j = lane + 64 * k;
+        v[k] = j < n ? __expf(v[k] - mx) : 0.f;
+        sum += v[k];
+    }
+    sum = wave_sum(sum);
+    const float inv = 1.0f / sum;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int j = lane + 64 * k;
+        if (j < ldp) o[j] = f32_to_bf16(v[k] * inv);
+    }
+}
+
 inline unsigned grid_for(int64_t total, int per_block = 256, int64_t cap = 16384) {
     int64_t nb = (total + per_block - 1) / per_block;
     if (nb > cap) nb = cap;
@@ -344,5 +383,18 @@ extern "C" int yume_frames_u8(const float* video, int64_t C, int64_t T, int64_t 
         default: hipLaunchKernelGGL((frames_u8_kernel<4>), dim3(grid_for(nquad)), dim3(256), 0, st, video, plane, nquad, o); break;
     }
     YUME_CHECK_LAUNCH("frames_u8");
+    return YUME_OK;
+}
+
+extern "C" int yume_softmax_bias_rows(const float* S, int64_t lds, int64_t strideS, int64_t H, int64_t n, const float* bias,
+                                      int64_t ldb, void* P, int64_t ldp, int64_t strideP, void* stream) {
+    YUME_REQUIRE(S && bias && P, "softmax_bias_rows: NULL pointer");
+    YUME_REQUIRE(H > 0 && n > 0 && n <= 1024 && ldp >= n && ldp <= 1024 && lds >= n && ldb >= 2 * n - 1,
+                 "softmax_bias_rows: bad shape H=%lld n=%lld lds=%lld ldp=%lld ldb=%lld", (long long)H, (long long)n, (long long)lds,
+                 (long long)ldp, (long long)ldb);
+    const int64_t rows = H * n;
+    hipLaunchKernelGGL(softmax_bias_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, S, lds, strideS,
+                       (int)n, bias, ldb, (unsigned short*)P, ldp, strideP, rows);
+    YUME_CHECK_LAUNCH("softmax_bias_rows");
     return YUME_OK;
 }

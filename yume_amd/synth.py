@@ -283,3 +283,46 @@ def make_vae_state_dict(cfg, seed=0, device="cpu"):
             v = _uniform(shape, math.sqrt(3.0 / fan_in), g)
         sd[k] = v.to(device)
     return sd
+
+
+# ---------------------------------------------------------------------------------------------- umT5 text encoder
+T5_CFG_XXL = dict(vocab=256384, dim=4096, dim_attn=4096, dim_ffn=10240, num_heads=64, num_layers=24, num_buckets=32,
+                  shared_pos=False)
+
+
+def tiny_t5_cfg(dim=256, heads=4, ffn=512, layers=2, vocab=1000):
+    """umT5 architecture (per-layer relative-position embeddings, head_dim 64) at test size."""
+    return dict(vocab=vocab, dim=dim, dim_attn=heads * 64, dim_ffn=ffn, num_heads=heads, num_layers=layers, num_buckets=32,
+                shared_pos=False)
+
+
+def t5_param_shapes(cfg):
+    C, Da, F, H = cfg["dim"], cfg["dim_attn"], cfg["dim_ffn"], cfg["num_heads"]
+    sh = {"token_embedding.weight": (cfg["vocab"], C), "norm.weight": (C,)}
+    for i in range(cfg["num_layers"]):
+        p = f"blocks.{i}."
+        sh.update({p + "norm1.weight": (C,), p + "norm2.weight": (C,), p + "attn.q.weight": (Da, C), p + "attn.k.weight": (Da, C),
+                   p + "attn.v.weight": (Da, C), p + "attn.o.weight": (C, Da), p + "ffn.gate.0.weight": (F, C),
+                   p + "ffn.fc1.weight": (F, C), p + "ffn.fc2.weight": (C, F),
+                   p + "pos_embedding.embedding.weight": (cfg["num_buckets"], H)})
+    return sh
+
+
+def make_t5_state_dict(cfg, seed=0, device="cpu"):
+    """Deterministic per-key weights: projections ~ fan_in^-1/2 (q additionally / sqrt(head_dim) so the unscaled T5 logits stay
+    O(1)), norm weights 1 +- 0.1, relative-position embeddings ~ N(0, 0.5), token embeddings ~ N(0, 1)."""
+    sd = {}
+    for k, shape in t5_param_shapes(cfg).items():
+        g = _gen(seed, k)
+        if k.endswith("norm.weight") or "norm1" in k or "norm2" in k:
+            v = 1.0 + 0.1 * torch.randn(shape, generator=g)
+        elif k == "token_embedding.weight":
+            v = torch.randn(shape, generator=g)
+        elif "pos_embedding" in k:
+            v = 0.5 * torch.randn(shape, generator=g)
+        else:
+            v = torch.randn(shape, generator=g) * shape[1] ** -0.5
+            if k.endswith("attn.q.weight"):
+                v = v / 8.0
+        sd[k] = v.to(device)
+    return sd
