@@ -133,3 +133,33 @@ def ref_t5():
             torch.cuda.current_device = real
         _cache["t5"] = m
     return _cache["t5"]
+
+
+def ref_clip():
+    """Returns the reference wan/modules/clip.py (vision tower). Stand-ins: torchvision.transforms (not installed; only used to
+    build the PIL preprocessing pipeline), `.tokenizers`, `.xlm_roberta` (text tower base class, never instantiated here) and
+    `.attention.flash_attention` (exact softmax, as for the DiT)."""
+    assert available(), "reference tree not present"
+    if "clip" not in _cache:
+        if "torchvision" not in sys.modules:
+            tv = types.ModuleType("torchvision")
+            tvt = types.ModuleType("torchvision.transforms")
+            tv.transforms = tvt
+            sys.modules["torchvision"] = tv
+            sys.modules["torchvision.transforms"] = tvt
+        pkg = "yume_ref_clippkg"
+        root = types.ModuleType(pkg)
+        root.__path__ = [os.path.join(REF_ROOT, "wan", "modules")]
+        tok = types.ModuleType(pkg + ".tokenizers")
+        tok.HuggingfaceTokenizer = type("HuggingfaceTokenizer", (), {})
+        xlm = types.ModuleType(pkg + ".xlm_roberta")
+        xlm.XLMRoberta = type("XLMRoberta", (nn.Module,), {})
+        att = types.ModuleType(pkg + ".attention")
+        att.flash_attention = sdpa_standin
+        sys.modules.update({pkg: root, pkg + ".tokenizers": tok, pkg + ".xlm_roberta": xlm, pkg + ".attention": att})
+        spec = importlib.util.spec_from_file_location(pkg + ".clip", os.path.join(REF_ROOT, "wan", "modules", "clip.py"))
+        m = importlib.util.module_from_spec(spec)
+        sys.modules[pkg + ".clip"] = m
+        spec.loader.exec_module(m)
+        _cache["clip"] = m
+    return _cache["clip"]

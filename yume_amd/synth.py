@@ -326,3 +326,47 @@ def make_t5_state_dict(cfg, seed=0, device="cpu"):
                 v = v / 8.0
         sd[k] = v.to(device)
     return sd
+
+
+# ---------------------------------------------------------------------------------------------- CLIP vision tower
+CLIP_CFG_VIT_H = dict(image_size=224, patch_size=14, dim=1280, mlp_ratio=4, out_dim=1024, num_heads=16, num_layers=32,
+                      pool_type="token", pre_norm=True, post_norm=False, activation="gelu", norm_eps=1e-5)
+
+
+def tiny_clip_cfg(dim=320, heads=4, layers=3, image=56, patch=14):
+    """ViT-H/14 architecture (head_dim 80, pre-norm, nn.GELU, token pooling) at test size: 16 patches + cls."""
+    return dict(image_size=image, patch_size=patch, dim=dim, mlp_ratio=4, out_dim=64, num_heads=heads, num_layers=layers,
+                pool_type="token", pre_norm=True, post_norm=False, activation="gelu", norm_eps=1e-5)
+
+
+def clip_param_shapes(cfg):
+    C, ps = cfg["dim"], cfg["patch_size"]
+    n = (cfg["image_size"] // ps) ** 2 + 1
+    M = int(C * cfg["mlp_ratio"])
+    sh = {"cls_embedding": (1, 1, C), "pos_embedding": (1, n, C), "head": (C, cfg["out_dim"]), "patch_embedding.weight": (C, 3, ps, ps),
+          "pre_norm.weight": (C,), "pre_norm.bias": (C,), "post_norm.weight": (C,), "post_norm.bias": (C,)}
+    for i in range(cfg["num_layers"]):
+        p = f"transformer.{i}."
+        sh.update({p + "norm1.weight": (C,), p + "norm1.bias": (C,), p + "norm2.weight": (C,), p + "norm2.bias": (C,),
+                   p + "attn.to_qkv.weight": (3 * C, C), p + "attn.to_qkv.bias": (3 * C,), p + "attn.proj.weight": (C, C),
+                   p + "attn.proj.bias": (C,), p + "mlp.0.weight": (M, C), p + "mlp.0.bias": (M,), p + "mlp.2.weight": (C, M),
+                   p + "mlp.2.bias": (C,)})
+    return sh
+
+
+def make_clip_state_dict(cfg, seed=0, device="cpu"):
+    sd = {}
+    for k, shape in clip_param_shapes(cfg).items():
+        g = _gen(seed, "clip." + k)
+        if "norm" in k:
+            v = (1.0 if k.endswith("weight") else 0.0) + 0.1 * torch.randn(shape, generator=g)
+        elif k.endswith("bias"):
+            v = 0.05 * torch.randn(shape, generator=g)
+        elif k in ("cls_embedding", "pos_embedding"):
+            v = 0.5 * torch.randn(shape, generator=g)
+        elif k == "patch_embedding.weight":
+            v = torch.randn(shape, generator=g) * (shape[1] * shape[2] * shape[3]) ** -0.5
+        else:
+            v = torch.randn(shape, generator=g) * shape[-1 if k == "head" else 1] ** -0.5
+        sd[k] = v.to(device)
+    return sd
