@@ -314,3 +314,33 @@ def test_errors_are_loud():
         ops.gemm_bf16(a, w, None, o)
     with pytest.raises(RuntimeError, match="device"):
         ops.gemm_bf16(a.cpu(), w, None, o)
+
+
+def test_gemm_auto_row_split_between_kernels():
+    """variant 0 when the 256x256 tiling leaves a nearly empty last round (here 37 x 28 = 1036 tiles = 4 rounds + 12): whole
+    rounds of M-tiles on the 256x256 kernel, the remaining rows on the 128x128 kernel — every epilogue's row-dependent operand
+    (residual rows, gate row selector, K-major transposed columns) must follow the split."""
+    M, N, K = 9460, 7168, 256
+    a, w, bias = rnd(M, K, seed=1, dtype=torch.bfloat16).to(DEV), rnd(N, K, seed=2, scale=K ** -0.5, dtype=torch.bfloat16).to(DEV), rnd(N, seed=3).to(DEV)
+    x = rnd(M, N, seed=4).to(DEV)
+    tab = rnd(2, 6, N, seed=5).to(DEV)
+    idx = (torch.arange(M) % 2).to(torch.int32).to(DEV)
+    for variant_ref in (2,):
+        want = ops.gemm_bf16(a, w, bias, x.clone(), ops.EPI_RESID, gate=tab[:, 2], gate_stride=6 * N, row_idx=idx, variant=variant_ref)
+        got = ops.gemm_bf16(a, w, bias, x.clone(), ops.EPI_RESID, gate=tab[:, 2], gate_stride=6 * N, row_idx=idx, variant=0)
+        assert (got - want).abs().max() <= 2e-5 * want.abs().max()
+    Mp = (M + 7) // 8 * 8
+    ns = N - 1024
+
+    def splitt(variant):
+        qk = torch.empty(M, ns, dtype=torch.bfloat16, device=DEV)
+        vt = torch.zeros(N - ns, Mp, dtype=torch.bfloat16, device=DEV)
+        ops.gemm_bf16(a, w, bias, qk, ops.EPI_BF16_SPLITT, out_t=vt, n_split=ns, variant=variant)
+        return qk.float(), vt.float()
+    (q2, v2), (q0, v0) = splitt(2), splitt(0)
+    assert (q0 - q2).abs().max() <= 2.0 ** -7 * q2.abs().max() and (v0 - v2).abs().max() <= 2.0 ** -7 * v2.abs().max()
+    assert (v0[:, M:] == 0).all()
+    og, og2 = torch.empty(M, N, dtype=torch.bfloat16, device=DEV), torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    ops.gemm_bf16(a, w, bias, og, ops.EPI_BF16_GELU, variant=0)
+    ops.gemm_bf16(a, w, bias, og2, ops.EPI_BF16_GELU, variant=2)
+    assert (og.float() - og2.float()).abs().max() <= 2.0 ** -7 * og2.float().abs().max()

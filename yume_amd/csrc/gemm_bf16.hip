@@ -23,6 +23,23 @@ extern "C" int yume_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t
     p.tiles_n = (int)((N + BN - 1) / BN);
     p.group_m = 8;
     p.bsW = 0; p.bsO = 0;
+    if (variant == 0 && epi != YUME_EPI_BF16_GEGLU && use_256(p, 0, epi != YUME_EPI_BF16_SPLITT || (n_split % 256) == 0)) {
+        // Row split (same idea as the attention's query split): when the 256x256 tiling leaves a last round that is at
+        // most ~1/3 full (ffn.0 at L = 9460: 2072 tiles = 8 rounds + 24; QKV: 5 rounds + 52), run whole rounds of
+        // M-tiles on the 256x256 kernel and the remaining rows (a few hundred) on the 128x128 kernel.
+        const int64_t tn = (N + 255) / 256, tm = (M + 255) / 256, T = tm * tn, R = T % 256, full = T - R;
+        const int64_t m_main = full / tn, M_main = m_main * 256, rem = M - M_main;
+        if (R > 0 && R <= 96 && full >= 256 && m_main >= 1 && rem > 0 && rem <= 1024) {
+            int rc = yume_gemm_bf16(A, lda, W, ldw, bias, M_main, N, K, epi, out, ldo, gate, gate_stride, row_idx, outT, ldt, n_split,
+                                    2, stream);
+            if (rc != YUME_OK) return rc;
+            const int64_t osz = (epi == YUME_EPI_F32 || epi == YUME_EPI_RESID) ? 4 : 2;
+            return yume_gemm_bf16(reinterpret_cast<const unsigned short*>(A) + M_main * lda, lda, W, ldw, bias, rem, N, K, epi,
+                                  reinterpret_cast<char*>(out) + M_main * ldo * osz, ldo, gate, gate_stride,
+                                  row_idx ? row_idx + M_main : nullptr,
+                                  outT ? reinterpret_cast<unsigned short*>(outT) + M_main : nullptr, ldt, n_split, 1, stream);
+        }
+    }
     PlainA al;
     al.A = (const unsigned short*)A; al.lda = lda; al.M = (int)M; al.bsA = 0;
     Epilogue e = {};
