@@ -220,4 +220,6 @@ def test_full_resolution_wan21_decoder_is_causal():
     head = vae.decode([z[:, :4].contiguous()])[0]
     assert full.shape == (3, 49, 544, 960) and head.shape == (3, 13, 544, 960)
     assert torch.isfinite(full).all() and full.abs().max() <= 1.0
-    assert torch.equal(head, full[:, :13])
+    # not bit-equal: the 1x1x1 conv on all T latents at once is a plain GEMM whose kernel choice (256x256 rounds + 128x128
+    # remainder rows) depends on T; the two tilings differ in the last fp32 bits, which the bf16 activations then amplify
+    assert rel_l2(head, full[:, :13]) < 2e-3 and (head - full[:, :13]).abs().max() < 5e-2
