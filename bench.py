@@ -317,7 +317,8 @@ def main():
             "cached_context_ms_per_step": cached_ms,
             "model_tflop_per_step": flops_fwd_5b(L, n=cfg["num_layers"]) / 1e12,
             "model_tflops_per_gpu": flops_fwd_5b(L, n=cfg["num_layers"]) / 1e12 / (ms_per_step * 1e-3),
-            "roofline": {"bound": "mfma", "kernel": "gemm256_kernel<EPI_BF16_GELU, PlainA> ffn.0 9460x14336x3072",
+            "roofline": {"bound": "mfma", "kernel": "ffn.0 GEMM 9460x14336x3072 + bias + GELU: gemm256_kernel<EPI_BF16_GELU, PlainA> on rows 0..9215 "
+                                                       "+ gemm128_kernel on the last 244 rows (one yume_gemm_bf16 call, timed as one launch)",
                          "achieved": achieved, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / MFMA_BF16_PEAK_TFLOPS, "traffic": pmc_traffic_bytes(),
                          "launch_ms": gemm_ms, "launches_timed": len(prof)},
