@@ -204,6 +204,25 @@ def test_context_cache_is_bit_identical(name):
     assert not torch.equal(want3, want2)
 
 
+def test_prompt_length_edge_cases():
+    """Empty prompt (the reference pads [0, text_dim] to text_len zero rows, model.py:816-821), a single token, exactly
+    text_len tokens — against the oracle; one token more than text_len is an error."""
+    fx = load_golden("dit_wan23_packed_f13")
+    cfg = fx["cfg"]
+    sd = synth.make_dit_state_dict(cfg, fx["family"], fx["seed"])
+    m = build_model(fx["family"], cfg, sd)
+    x = fx["inputs"]["x"]
+    g = torch.Generator().manual_seed(21)
+    for n in (0, 1, cfg["text_len"]):
+        ctx = torch.randn(n, cfg["text_dim"], generator=g)
+        want = odit.forward_wan23(sd, cfg, x, fx["t"], ctx, fx["seq_len"], fx["lfz"], True)
+        got = m([x.to(DEV)], t=fx["t"].to(DEV), context=[ctx.to(DEV)], seq_len=fx["seq_len"], latent_frame_zero=fx["lfz"], flag=True)[0].cpu()
+        assert rel_l2(got, want) <= 1.5e-2, (n, rel_l2(got, want))
+    with pytest.raises(RuntimeError):
+        m([x.to(DEV)], t=fx["t"].to(DEV), context=[torch.randn(cfg["text_len"] + 1, cfg["text_dim"]).to(DEV)], seq_len=fx["seq_len"],
+          latent_frame_zero=fx["lfz"], flag=True)
+
+
 # ---------------------------------------------------------------------------------- sequence parallel (Ulysses), §8(f).2
 def _sp_worker(rank, world, port, name, out_dir):
     import os

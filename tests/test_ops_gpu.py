@@ -175,7 +175,7 @@ def run_attn(q, k, v, scale=None, accumulate=None, variant=0):
     return out.cpu().view(Lq, H, D)
 
 
-@pytest.mark.parametrize("Lq,Lk,H", [(128, 64, 1), (32, 128, 2), (300, 300, 3), (1000, 512, 4), (517, 257, 2), (2048, 2048, 8),
+@pytest.mark.parametrize("Lq,Lk,H", [(1, 1, 2), (1, 300, 2), (300, 1, 2), (5, 63, 1), (128, 64, 1), (32, 128, 2), (300, 300, 3), (1000, 512, 4), (517, 257, 2), (2048, 2048, 8),
                                      (64, 1, 1), (1, 77, 3), (130, 1000, 24), (200, 640, 2), (100, 65, 1)])
 @pytest.mark.parametrize("variant", [0, 1, 2, 4])
 def test_attention_matches_exact_softmax(Lq, Lk, H, variant):

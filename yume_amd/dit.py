@@ -199,7 +199,10 @@ class DiTEngine:
         if n > m.text_len:
             raise RuntimeError(f"context has {n} tokens > text_len {m.text_len}")
         cpad = self._buf("ctx_in", (m.text_len, m.text_dim), torch.bfloat16)
-        ops.cast_bf16(context.to(device=self.dev, dtype=torch.float32).contiguous(), n, cpad)
+        if n:
+            ops.cast_bf16(context.to(device=self.dev, dtype=torch.float32).contiguous(), n, cpad)
+        else:
+            cpad.zero_()                       # empty prompt: the reference pads [0, text_dim] to text_len zero rows (model.py:816-821)
         hid = self._buf("ctx_hid", (m.text_len, m.dim), torch.bfloat16)
         ops.gemm_bf16(cpad, w0, b0, hid, EPI_BF16_GELU)
         ops.gemm_bf16(hid, w2, b2, out_rows, EPI_BF16)
