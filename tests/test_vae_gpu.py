@@ -218,3 +218,21 @@ def test_vae_chunk_semantics_single_frame_and_bf16_latents():
     got = vae.decode([z1.to(DEV).bfloat16()])[0].cpu()
     assert got.shape == want.shape == (3, 1, 64, 96)
     assert rel_l2(got, ovae.decode(sd, fx["cfg"], z1.bfloat16().float())) <= 3e-2
+
+
+@pytest.mark.parametrize("name", ["vae_22", "vae_21"])
+@pytest.mark.parametrize("T,hw", [(1, (32, 48)), (5, (32, 48)), (6, (32, 48)), (9, (48, 32))])
+def test_vae_encode_frame_count_and_size_edge_cases(name, T, hw):
+    """encode() of 1 frame (first-chunk path only), 1 + 4 frames, 1 + 4 + 1 frames (the reference uses 1 + 4*((T-1)//4) and
+    silently drops the rest, vae2_2.py:806-807) and a portrait size — against the oracle."""
+    fx = load_golden(name)
+    s = 16 if fx["version"] == "2.2" else 8
+    H, W = hw[0] * s // 16, hw[1] * s // 16
+    vae = build_vae(fx)
+    sd = synth.make_vae_state_dict(fx["cfg"], fx["seed"])
+    g = torch.Generator().manual_seed(T * 7 + H)
+    video = torch.rand(3, T, H, W, generator=g) * 2 - 1
+    want = ovae.encode(sd, fx["cfg"], video)
+    got = vae.encode([video.to(DEV)])[0].cpu()
+    assert got.shape == want.shape == (fx["cfg"]["z_dim"], 1 + (T - 1) // 4, H // s, W // s)
+    assert rel_l2(got, want) <= 3e-2, rel_l2(got, want)

@@ -144,20 +144,20 @@ class VaeEngine:
         """AttentionBlock: per frame, one head of width C over the H*W positions (two GEMMs + a row softmax)."""
         T, H, W, C = x.shape
         hw = H * W
-        if hw % 4 or C % 64:
-            raise RuntimeError("yume_amd VAE attention needs H*W % 4 == 0 and C % 64 == 0")
+        if C % 64:
+            raise RuntimeError("yume_amd VAE attention needs C % 64 == 0")
         pq = self.P[name + ".to_qkv"]
         xn = self._norm(name + ".norm", x, silu=False)
         out = torch.empty_like(x)
-        hwp = _ru(hw, 64)
-        qk = torch.empty((hw, 2 * C), dtype=torch.bfloat16, device=self.dev)
+        hwp, hw4 = _ru(hw, 64), _ru(hw, 4)     # K padding of the P.V product; N padding of the score GEMM (zero key rows)
+        qk = torch.zeros((hw4, 2 * C), dtype=torch.bfloat16, device=self.dev)
         vt = torch.zeros((C, hwp), dtype=torch.bfloat16, device=self.dev)
-        s = torch.empty((hw, hw), dtype=torch.float32, device=self.dev)
+        s = torch.empty((hw, hw4), dtype=torch.float32, device=self.dev)
         pm = torch.empty((hw, hwp), dtype=torch.bfloat16, device=self.dev)
         o = self._new(1, H, W, C)
         for t in range(T):
-            ops.gemm_bf16(xn[t].view(hw, C), pq["w"], pq["b"], qk, ops.EPI_BF16_SPLITT, out_t=vt, n_split=2 * C)
-            ops.gemm_bf16(qk[:, :C], qk[:, C:], None, s, ops.EPI_F32)
+            ops.gemm_bf16(xn[t].view(hw, C), pq["w"], pq["b"], qk[:hw], ops.EPI_BF16_SPLITT, out_t=vt, n_split=2 * C)
+            ops.gemm_bf16(qk[:hw, :C], qk[:, C:], None, s, ops.EPI_F32)
             V.softmax_rows(s, hw, 1.0 / math.sqrt(C), pm)
             ops.gemm_bf16(pm, vt, None, o.view(hw, C), ops.EPI_BF16)
             pp = self.P[name + ".proj"]
