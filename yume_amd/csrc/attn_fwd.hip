@@ -1,8 +1,13 @@
 // attn_fwd.hip — exact-softmax attention forward for head_dim 128, bf16 in / fp32 accumulate / bf16 out (gfx950).
 //
-// One workgroup = 4 waves = 128 queries of one head; each wave owns 32 queries and walks the
-// keys in tiles of 64. Everything is computed TRANSPOSED so that the softmax row of a query
-// lives in ONE lane (plus its partner lane^32) and never needs LDS or cross-lane shuffles:
+// Three kernels compute the same function (yume_attn_fwd picks; tests compare them):
+//   attn_fwd_kernel_v4  8 waves, 256 queries per workgroup, one workgroup per CU, software-pipelined across key tiles
+//                       (self-attention, Lk >= 1536); see the comment above it
+//   attn_fwd_kernel_v2  4 waves, 128 queries, two workgroups per CU, K / V^T tiles by LDS-DMA (cross-attention and the
+//                       query rows left over after whole rounds of v4 workgroups)
+//   attn_fwd_kernel     as v2 with register-staged tiles (the first version; kept as an independent cross-check)
+// Common to all: each wave owns 32 queries and walks the keys in tiles of 64. Everything is computed TRANSPOSED so that
+// the softmax row of a query lives in ONE lane (plus its partner lane^32) and never needs LDS or cross-lane shuffles:
 //
 //   S^T[key, q] = K[key, :] . Q[q, :]        v_mfma_f32_32x32x16_bf16, A = K tile (LDS), B = Q^T (registers)
 //                 C layout: col = lane&31 = q, row = key = (r&3) + 8*(r>>2) + 4*(lane>>5)
@@ -12,9 +17,8 @@
 //   O^T accumulators keep col = lane&31 = q, so the online-softmax rescale is lane-local too.
 //
 // K tile  : LDS [64 keys][128 d] bf16, 16-byte chunk c of row r stored at chunk c ^ (r & 15)  (ds_read_b128 conflict-free)
-// V^T tile: LDS [128 d][64 keys] bf16, row stride 136 B                                     (ds_read_b64 conflict-free)
-// Both tiles are register-staged (global -> VGPR issued one tile ahead, VGPR -> LDS after the
-// compute of the current tile) and double buffered in LDS: one barrier per key tile.
+// V^T tile: LDS [128 d][64 keys] bf16; v1: row stride 136 B (ds_read_b64); v2 / v4: 128-byte rows, chunk c of row d at
+//           chunk c ^ ((d >> 1) & 7), the swizzle applied on the SOURCE address of the LDS-DMA
 // Roofline: MFMA (bf16 dense). Algorithmic work 4*Lq*Lk*128 flop per head.
 #include "common.hpp"
 
