@@ -11,7 +11,6 @@ Parity pin: diffusers is not installed in this image, so the restatement is pinn
 the formula above (tests/test_frames.py), not to an execution of the dependency.
 Only tests/ may import this module.
 """
-import numpy as np
 import torch
 
 

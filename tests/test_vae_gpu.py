@@ -4,7 +4,6 @@
 Stated tolerance: the reference runs the VAE in fp32; the HIP path keeps bf16 activations/weights with fp32
 accumulation and fp32 norm statistics. SURVEY §8(c) measured the reference's own bf16-autocast deviation at rel-L2
 1.5e-2 (2.2) / 1.8e-2 (2.1) on decoder outputs; we require rel-L2 <= 3e-2 on decoded pixels and on encoded latents."""
-import math
 import sys
 
 import pytest

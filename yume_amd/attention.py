@@ -6,7 +6,6 @@ Same signature and return convention as the reference wrapper around flash-attn'
 route the reference model's attention through the gfx950 kernel.
 """
 import math
-import warnings
 
 import torch
 

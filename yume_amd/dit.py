@@ -17,7 +17,6 @@ goes through this engine:
 HBM layout (L tokens, C hidden): residual stream x fp32 [L, C]; GEMM operands bf16 row-major [L, K];
 q|k bf16 [L, 2C]; V^T bf16 [C, Lpad] (K-major, per head 128 rows); modulation tables fp32 [blocks, R, 6, C].
 """
-import math
 
 import torch
 
