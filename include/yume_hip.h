@@ -286,6 +286,13 @@ int yume_gemm_bf16_batched(const void* A, int64_t lda, int64_t strideA, const vo
                            int64_t batch, int variant, void* stream);
 int yume_softmax_bias_rows(const float* S, int64_t lds, int64_t strideS, int64_t H, int64_t n, const float* bias,
                            int64_t ldb, void* P, int64_t ldp, int64_t strideP, void* stream);
+/* split-K for the encoders' small-M GEMMs (M <= 512 tokens against tens of MB of weights — every nn.Linear of t5.py / clip.py):
+ * K is cut into `splits` slices computed side by side on the 128x128 kernel (fp32 partials in `workspace`,
+ * yume_gemm_splitk_workspace_bytes = splits*M*N*4, caller-owned), then summed in a fixed order with bias + epilogue
+ * (YUME_EPI_F32 / RESID without gate / BF16 / BF16_GELU / BF16_GELU_ERF / BF16_GEGLU). K % (splits*64) == 0, N % 8 == 0. */
+int64_t yume_gemm_splitk_workspace_bytes(int64_t M, int64_t N, int splits);
+int yume_gemm_bf16_splitk(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, int64_t M, int64_t N,
+                          int64_t K, int epi, void* out, int64_t ldo, int splits, void* workspace, void* stream);
 
 #ifdef __cplusplus
 }

@@ -344,3 +344,28 @@ def test_gemm_auto_row_split_between_kernels():
     ops.gemm_bf16(a, w, bias, og, ops.EPI_BF16_GELU, variant=0)
     ops.gemm_bf16(a, w, bias, og2, ops.EPI_BF16_GELU, variant=2)
     assert (og.float() - og2.float()).abs().max() <= 2.0 ** -7 * og2.float().abs().max()
+
+
+@pytest.mark.parametrize("M,N,K", [(77, 4096, 4096), (512, 1280, 5120), (257, 2048, 1024), (3, 256, 512)])
+def test_gemm_small_m_split_k_matches_plain(M, N, K):
+    """split-K path of the encoders' small-M GEMMs: every supported epilogue against the one-pass kernels."""
+    a = rnd(M, K, seed=1, dtype=torch.bfloat16).to(DEV)
+    w = rnd(N, K, seed=2, scale=K ** -0.5, dtype=torch.bfloat16).to(DEV)
+    bias = rnd(N, seed=3).to(DEV)
+    for epi, odt, ncol in ((ops.EPI_F32, torch.float32, N), (ops.EPI_BF16, torch.bfloat16, N), (ops.EPI_BF16_GELU_ERF, torch.bfloat16, N),
+                           (ops.EPI_BF16_GELU, torch.bfloat16, N)):
+        want = ops.gemm_bf16(a, w, bias, torch.empty(M, ncol, dtype=odt, device=DEV), epi)
+        got = ops.gemm_small_m(a, w, bias, torch.empty(M, ncol, dtype=odt, device=DEV), epi)
+        tol = 2e-5 if odt == torch.float32 else 2.0 ** -7
+        assert (got.float() - want.float()).abs().max() <= tol * max(1.0, want.float().abs().max().item())
+    x = rnd(M, N, seed=4).to(DEV)
+    want = ops.gemm_bf16(a, w, bias, x.clone(), ops.EPI_RESID)
+    got = ops.gemm_small_m(a, w, bias, x.clone(), ops.EPI_RESID)
+    assert (got - want).abs().max() <= 2e-5 * want.abs().max()
+    want = ops.gemm_bf16(a, w, None, torch.empty(M, N // 2, dtype=torch.bfloat16, device=DEV), ops.EPI_BF16_GEGLU, variant=2)
+    got = ops.gemm_small_m(a, w, None, torch.empty(M, N // 2, dtype=torch.bfloat16, device=DEV), ops.EPI_BF16_GEGLU)
+    assert (got.float() - want.float()).abs().max() <= 2.0 ** -7 * max(1.0, want.float().abs().max().item())
+    # and against the exact product
+    ref = gemm_ref(a.cpu(), w.cpu(), bias.cpu())
+    o32 = ops.gemm_small_m(a, w, bias, torch.empty(M, N, dtype=torch.float32, device=DEV), ops.EPI_F32)
+    assert (o32.cpu().double() - ref).abs().max() < 1e-4 * max(1.0, ref.abs().max().item())

@@ -21,6 +21,8 @@ SIGNATURES = {
     "yume_gemm_bf16": [_P, _L, _P, _L, _P, _L, _L, _L, _I, _P, _L, _P, _L, _P, _P, _L, _L, _I, _P],
     "yume_rmsnorm_f32": [_P, _L, _L, _L, _F, _P, _P, _L, _P],
     "yume_gemm_bf16_batched": [_P, _L, _L, _P, _L, _L, _L, _L, _L, _I, _P, _L, _L, _L, _I, _P],
+    "yume_gemm_splitk_workspace_bytes": [_L, _L, _I],
+    "yume_gemm_bf16_splitk": [_P, _L, _P, _L, _P, _L, _L, _L, _I, _P, _L, _I, _P, _P],
     "yume_softmax_bias_rows": [_P, _L, _L, _L, _L, _P, _L, _P, _L, _L, _P],
     "yume_rmsnorm_rope": [_P, _L, _L, _L, _I, _P, _F, _P, _L, _P],
     "yume_attn_fwd": [_P, _L, _P, _L, _P, _L, _P, _L, _L, _L, _L, _F, _I, _I, _P],
@@ -41,7 +43,7 @@ SIGNATURES = {
     "yume_frames_u8": [_P, _L, _L, _L, _L, _P, _P],
     "yume_vae_unpack_output": [_P, _L, _L, _L, _L, _L, _I, _P, _P, _F, _F, _P, _P],
 }
-_RES = {"yume_last_error": c_char_p, "yume_target_arch": c_char_p}
+_RES = {"yume_last_error": c_char_p, "yume_target_arch": c_char_p, "yume_gemm_splitk_workspace_bytes": c_int64}
 
 _lib = None
 

@@ -169,10 +169,10 @@ class ClipEngine:
             ops.adaln_modulate(x, d["n1w"], d["n1b"], 0, None, False, h, 0, eps=d["eps"])
             ops.gemm_bf16(h, d["wqkv"], d["bqkv"], qk, ops.EPI_BF16_SPLITT, out_t=vt, n_split=2 * H * 128)
             ops.attn_fwd(qk[:, :H * 128], qk[:, H * 128:], vt, att, L, L, H, scale=scale)
-            ops.gemm_bf16(att, d["wo"], d["bo"], x, ops.EPI_RESID)
+            ops.gemm_small_m(att, d["wo"], d["bo"], x, ops.EPI_RESID)
             ops.adaln_modulate(x, d["n2w"], d["n2b"], 0, None, False, h, 0, eps=d["eps"])
-            ops.gemm_bf16(h, d["w1"], d["b1"], ff, ops.EPI_BF16_GELU_ERF)
-            ops.gemm_bf16(ff, d["w2"], d["b2"], x, ops.EPI_RESID)
+            ops.gemm_small_m(h, d["w1"], d["b1"], ff, ops.EPI_BF16_GELU_ERF)
+            ops.gemm_small_m(ff, d["w2"], d["b2"], x, ops.EPI_RESID)
         return x.clone()
 
 

@@ -102,3 +102,78 @@ extern "C" int yume_gemm_bf16_batched(const void* A, int64_t lda, int64_t stride
     if (epi == YUME_EPI_F32) return launch<YUME_EPI_F32>(p, al, e, st, "gemm_bf16_batched", (int)batch);
     return launch<YUME_EPI_BF16>(p, al, e, st, "gemm_bf16_batched", (int)batch);
 }
+
+// ---- split-K for small-M, weight-streaming GEMMs (text / vision encoders: M <= 512 tokens against N x K weights of tens of MB)
+// With M <= 512 the 128x128 tiling has at most 4 * N/128 workgroups (32..160 for the encoder shapes): a fraction of the 256
+// CUs streams the weights and the GEMM runs at ~1 TB/s. Here K is cut into `splits` slices computed side by side (the batched
+// launch, gridDim.y = splits, fp32 partials in the caller's workspace [splits, M, N]) and a second kernel sums the slices in a
+// fixed order and applies bias + epilogue. HBM-bound: algorithmic bytes = N*K*2 (the weights, read once).
+namespace {
+template <int EPI>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, int splits, int64_t MN, int N,
+                                                            const float* __restrict__ bias, void* __restrict__ out, int64_t ldo) {
+    const int64_t nq = MN >> 2;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nq; i += (int64_t)gridDim.x * blockDim.x) {
+        f32x4 v = *reinterpret_cast<const f32x4*>(ws + 4 * i);
+        for (int s = 1; s < splits; ++s) v += *reinterpret_cast<const f32x4*>(ws + s * MN + 4 * i);
+        const int64_t m = (4 * i) / N;
+        const int n = (int)((4 * i) - m * N);
+        if (bias) v += *reinterpret_cast<const f32x4*>(bias + n);
+        if (EPI == YUME_EPI_F32) {
+            *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(out) + m * ldo + n) = v;
+        } else if (EPI == YUME_EPI_RESID) {
+            float* xo = reinterpret_cast<float*>(out) + m * ldo + n;
+            *reinterpret_cast<f32x4*>(xo) = *reinterpret_cast<const f32x4*>(xo) + v;
+        } else if (EPI == YUME_EPI_BF16_GEGLU) {
+            const unsigned o = pack_bf16x2(v[1] * gelu_tanh(v[0]), v[3] * gelu_tanh(v[2]));
+            *reinterpret_cast<unsigned*>(reinterpret_cast<unsigned short*>(out) + m * ldo + (n >> 1)) = o;
+        } else {
+            if (EPI == YUME_EPI_BF16_GELU) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] = gelu_tanh(v[q]);
+            }
+            if (EPI == YUME_EPI_BF16_GELU_ERF) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] = 0.5f * v[q] * (1.0f + erff(v[q] * 0.7071067811865476f));
+            }
+            u32x2 o;
+            o[0] = pack_bf16x2(v[0], v[1]);
+            o[1] = pack_bf16x2(v[2], v[3]);
+            *reinterpret_cast<u32x2*>(reinterpret_cast<unsigned short*>(out) + m * ldo + n) = o;
+        }
+    }
+}
+}  // namespace
+
+extern "C" int64_t yume_gemm_splitk_workspace_bytes(int64_t M, int64_t N, int splits) { return (int64_t)splits * M * N * 4; }
+
+extern "C" int yume_gemm_bf16_splitk(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, int64_t M, int64_t N,
+                                     int64_t K, int epi, void* out, int64_t ldo, int splits, void* workspace, void* stream) {
+    YUME_REQUIRE(A && W && out && workspace, "gemm_bf16_splitk: NULL pointer");
+    YUME_REQUIRE(splits >= 1 && splits <= 64 && (K % (splits * BK)) == 0, "gemm_bf16_splitk: K=%lld must be a multiple of splits*%d (splits=%d)",
+                 (long long)K, BK, splits);
+    YUME_REQUIRE(M > 0 && N > 0 && (N % 8) == 0 && (ldo % 4) == 0, "gemm_bf16_splitk: N must be a multiple of 8, ldo of 4");
+    YUME_REQUIRE(((uintptr_t)workspace % 16) == 0 && ((uintptr_t)out % 16) == 0, "gemm_bf16_splitk: pointers must be 16-byte aligned");
+    YUME_REQUIRE((M * N) % 4 == 0, "gemm_bf16_splitk: M*N must be a multiple of 4");
+    const int64_t Ks = K / splits;
+    int rc = yume_gemm_bf16_batched(A, lda, Ks, W, ldw, Ks, M, N, Ks, YUME_EPI_F32, workspace, N, M * N, splits, 1, stream);
+    if (rc != YUME_OK) return rc;
+    const int64_t MN = M * N;
+    const unsigned grid = (unsigned)((MN / 4 + 255) / 256 > 16384 ? 16384 : (MN / 4 + 255) / 256);
+    hipStream_t st = (hipStream_t)stream;
+    const float* ws = (const float*)workspace;
+#define YUME_RED(E) hipLaunchKernelGGL((splitk_reduce_kernel<E>), dim3(grid), dim3(256), 0, st, ws, splits, MN, (int)N, bias, out, ldo)
+    switch (epi) {
+        case YUME_EPI_F32: YUME_RED(YUME_EPI_F32); break;
+        case YUME_EPI_RESID: YUME_RED(YUME_EPI_RESID); break;
+        case YUME_EPI_BF16: YUME_RED(YUME_EPI_BF16); break;
+        case YUME_EPI_BF16_GELU: YUME_RED(YUME_EPI_BF16_GELU); break;
+        case YUME_EPI_BF16_GELU_ERF: YUME_RED(YUME_EPI_BF16_GELU_ERF); break;
+        case YUME_EPI_BF16_GEGLU: YUME_RED(YUME_EPI_BF16_GEGLU); break;
+        default:
+            yume_set_error("gemm_bf16_splitk: unsupported epilogue %d", epi);
+            return YUME_EINVAL;
+    }
+    YUME_CHECK_LAUNCH("gemm_bf16_splitk");
+    return YUME_OK;
+}

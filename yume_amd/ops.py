@@ -9,7 +9,7 @@ import torch
 
 from . import _lib
 
-EPI_BF16, EPI_BF16_GELU, EPI_F32, EPI_RESID, EPI_BF16_SPLITT, EPI_BF16_GELU_ERF = 0, 1, 2, 3, 4, 5
+EPI_BF16, EPI_BF16_GELU, EPI_F32, EPI_RESID, EPI_BF16_SPLITT, EPI_BF16_GELU_ERF, EPI_BF16_GEGLU = 0, 1, 2, 3, 4, 5, 6
 
 
 def _stream():
@@ -67,6 +67,37 @@ def gemm_bf16(a, w, bias, out, epi=EPI_BF16, gate=None, gate_stride=0, row_idx=N
     rc = lib.yume_gemm_bf16(ap, lda, wp, ldw, _ptr(bias), M, N, K, epi, op, ldo, _ptr(gate), gate_stride,
                             _ptr(row_idx), tp, ldt, n_split, variant, _stream())
     _lib.check(rc, "yume_gemm_bf16")
+    return out
+
+
+_splitk_ws = {}
+
+
+def gemm_small_m(a, w, bias, out, epi=EPI_BF16, target_blocks=256):
+    """a @ w.T for a small number of rows against a large weight (encoders): split-K over enough slices to put ~target_blocks
+    workgroups on the chip; falls back to the plain call when no split is possible or needed."""
+    M, K = a.shape
+    N = w.shape[0]
+    tiles = ((M + 127) // 128) * ((N + 127) // 128)
+    splits = 1
+    while splits < 16 and tiles * splits * 2 <= target_blocks and K % (splits * 2 * 64) == 0 and K // (splits * 2) >= 256:
+        splits *= 2
+    if splits == 1 or N % 8 or (M * N) % 4:
+        return gemm_bf16(a, w, bias, out, epi, variant=2 if epi == EPI_BF16_GEGLU else 0)
+    lib = _lib.load()
+    _dev(a, "a", torch.bfloat16)
+    _dev(w, "w", torch.bfloat16)
+    ap, lda = _rows(a, "a")
+    wp, ldw = _rows(w, "w")
+    op, ldo = _rows(out, "out")
+    need = splits * M * N
+    key = a.device.index
+    ws = _splitk_ws.get(key)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(max(need, 1 << 22), dtype=torch.float32, device=a.device)
+        _splitk_ws[key] = ws
+    rc = lib.yume_gemm_bf16_splitk(ap, lda, wp, ldw, _ptr(bias), M, N, K, epi, op, ldo, splits, ws.data_ptr(), _stream())
+    _lib.check(rc, "yume_gemm_bf16_splitk")
     return out
 
 

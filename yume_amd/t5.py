@@ -212,11 +212,11 @@ class T5Engine:
             # att[:, head h] = P[h] . v_h : W = the K-major V^T rows of head h
             _lib.check(lib.yume_gemm_bf16_batched(Pm.data_ptr(), npad, n * npad, vt.data_ptr(), npad, hd * npad, n, hd, npad,
                                                   ops.EPI_BF16, att.data_ptr(), Da, hd, H, 0, st), "yume_gemm_bf16_batched")
-            ops.gemm_bf16(att, d["wo"], None, x, ops.EPI_RESID)
+            ops.gemm_small_m(att, d["wo"], None, x, ops.EPI_RESID)
             _lib.check(lib.yume_rmsnorm_f32(x.data_ptr(), C, n, C, m.blocks[0].norm2.eps, d["n2"].data_ptr(), h.data_ptr(), C, st),
                        "yume_rmsnorm_f32")
-            ops.gemm_bf16(h, d["wgeglu"], None, ff, EPI_BF16_GEGLU, variant=2)
-            ops.gemm_bf16(ff, d["w2"], None, x, ops.EPI_RESID)
+            ops.gemm_small_m(h, d["wgeglu"], None, ff, EPI_BF16_GEGLU)          # split-K; falls back to the 256x256 GEGLU kernel
+            ops.gemm_small_m(ff, d["w2"], None, x, ops.EPI_RESID)
         _lib.check(lib.yume_rmsnorm_f32(x.data_ptr(), C, n, C, m.norm.eps, self.P["norm"].data_ptr(), h.data_ptr(), C, st),
                    "yume_rmsnorm_f32")
         return h.float()
