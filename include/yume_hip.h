@@ -109,6 +109,11 @@ int yume_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, const
  */
 int yume_rmsnorm_rope(void* buf, int64_t ld, int64_t T, int64_t C, int nparts,
                       const float* w, float eps, const float* rope, int64_t D, void* stream);
+/* same RMSNorm (no RoPE) with a per-row weight: row t uses w[(t % wperiod), :]. Normalises the cross-attention K of ALL
+ * blocks (wan23/modules/model.py:222-226, one WanRMSNorm per block) in one launch over the buffer [tokens, wperiod*C]
+ * viewed as [tokens*wperiod, C]. w: fp32 [wperiod, C]. */
+int yume_rmsnorm_rows_periodic(void* buf, int64_t ld, int64_t T, int64_t C, const float* w, int64_t wperiod, float eps,
+                               void* stream);
 
 /* ---- exact-softmax attention forward (FlashAttention-style, head_dim 128) -----------------
  * replaces: wan23/modules/attention.py:24-130 flash_attention() -> flash_attn_varlen_func

@@ -24,6 +24,7 @@ SIGNATURES = {
     "yume_gemm_splitk_workspace_bytes": [_L, _L, _I],
     "yume_gemm_bf16_splitk": [_P, _L, _P, _L, _P, _L, _L, _L, _I, _P, _L, _I, _P, _P],
     "yume_softmax_bias_rows": [_P, _L, _L, _L, _L, _P, _L, _P, _L, _L, _P],
+    "yume_rmsnorm_rows_periodic": [_P, _L, _L, _L, _P, _L, _F, _P],
     "yume_rmsnorm_rope": [_P, _L, _L, _L, _I, _P, _F, _P, _L, _P],
     "yume_attn_fwd": [_P, _L, _P, _L, _P, _L, _P, _L, _L, _L, _L, _F, _I, _I, _P],
     "yume_linear_smallm_f32": [_P, _L, _L, _P, _I, _P, _L, _I, _I, _P, _P, _P],

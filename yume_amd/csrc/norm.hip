@@ -101,9 +101,10 @@ __global__ __launch_bounds__(NT) void adaln_kernel(const float* __restrict__ x, 
 template <int NV>
 __global__ __launch_bounds__(NT) void rmsnorm_rope_kernel(unsigned short* __restrict__ buf, int64_t ld, int C,
                                                           int nparts, const float* __restrict__ w, float eps,
-                                                          const float* __restrict__ rope /*[T,64,2] or null*/) {
+                                                          const float* __restrict__ rope /*[T,64,2] or null*/, int wperiod) {
     __shared__ float red[8];
     const int64_t t = blockIdx.x;
+    if (wperiod > 1) w += (int64_t)(t % wperiod) * nparts * C;   // row t uses weight row t % wperiod (one launch for all layers' K)
     unsigned short* row = buf + t * ld;
     const int vpp = C >> 3;  // vectors per part
     const int nvec = vpp * nparts;
@@ -207,8 +208,24 @@ extern "C" int yume_rmsnorm_f32(const float* x, int64_t ldx, int64_t T, int64_t 
     return YUME_OK;
 }
 
+static int rmsnorm_rope_impl(void* buf, int64_t ld, int64_t T, int64_t C, int nparts, const float* w, float eps,
+                             const float* rope, int64_t D, int wperiod, void* stream);
+
 extern "C" int yume_rmsnorm_rope(void* buf, int64_t ld, int64_t T, int64_t C, int nparts, const float* w, float eps,
                                  const float* rope, int64_t D, void* stream) {
+    return rmsnorm_rope_impl(buf, ld, T, C, nparts, w, eps, rope, D, 1, stream);
+}
+
+// RMSNorm over C of T rows where row t takes weight row (t % wperiod): the K projections of all `wperiod` blocks' cross-attention
+// normalised in one launch (the buffer [tokens, wperiod*C] viewed as [tokens*wperiod, C])
+extern "C" int yume_rmsnorm_rows_periodic(void* buf, int64_t ld, int64_t T, int64_t C, const float* w, int64_t wperiod, float eps,
+                                          void* stream) {
+    YUME_REQUIRE(wperiod >= 1 && wperiod <= 1024, "rmsnorm_rows_periodic: wperiod %lld", (long long)wperiod);
+    return rmsnorm_rope_impl(buf, ld, T, C, 1, w, eps, nullptr, 128, (int)wperiod, stream);
+}
+
+static int rmsnorm_rope_impl(void* buf, int64_t ld, int64_t T, int64_t C, int nparts, const float* w, float eps,
+                             const float* rope, int64_t D, int wperiod, void* stream) {
     YUME_REQUIRE(buf && w, "rmsnorm_rope: NULL pointer");
     YUME_REQUIRE(nparts == 1 || nparts == 2, "rmsnorm_rope: nparts must be 1 or 2");
     YUME_REQUIRE(C > 0 && (C % 512) == 0 && C <= 8192, "rmsnorm_rope: C=%lld must be a multiple of 512 and <= 8192", (long long)C);
@@ -220,13 +237,13 @@ extern "C" int yume_rmsnorm_rope(void* buf, int64_t ld, int64_t T, int64_t C, in
     const int64_t nvec = (C / 8) * nparts;
     dim3 grid((unsigned)T), block(NT);
     if (nvec <= NT * 2)
-        hipLaunchKernelGGL(rmsnorm_rope_kernel<2>, grid, block, 0, st, b, ld, (int)C, nparts, w, eps, rope);
+        hipLaunchKernelGGL(rmsnorm_rope_kernel<2>, grid, block, 0, st, b, ld, (int)C, nparts, w, eps, rope, wperiod);
     else if (nvec <= NT * 3)
-        hipLaunchKernelGGL(rmsnorm_rope_kernel<3>, grid, block, 0, st, b, ld, (int)C, nparts, w, eps, rope);
+        hipLaunchKernelGGL(rmsnorm_rope_kernel<3>, grid, block, 0, st, b, ld, (int)C, nparts, w, eps, rope, wperiod);
     else if (nvec <= NT * 5)
-        hipLaunchKernelGGL(rmsnorm_rope_kernel<5>, grid, block, 0, st, b, ld, (int)C, nparts, w, eps, rope);
+        hipLaunchKernelGGL(rmsnorm_rope_kernel<5>, grid, block, 0, st, b, ld, (int)C, nparts, w, eps, rope, wperiod);
     else
-        hipLaunchKernelGGL(rmsnorm_rope_kernel<8>, grid, block, 0, st, b, ld, (int)C, nparts, w, eps, rope);
+        hipLaunchKernelGGL(rmsnorm_rope_kernel<8>, grid, block, 0, st, b, ld, (int)C, nparts, w, eps, rope, wperiod);
     YUME_CHECK_LAUNCH("rmsnorm_rope");
     return YUME_OK;
 }

@@ -99,20 +99,25 @@ class DiTEngine:
                 "nqk": f32(torch.cat([sa.norm_q.weight, sa.norm_k.weight])),
                 "wo": bf(sa.o.weight), "bo": f32(sa.o.bias),
                 "wq_c": bf(ca.q.weight), "bq_c": f32(ca.q.bias), "nq_c": f32(ca.norm_q.weight),
-                "wkv_c": bf(torch.cat([ca.k.weight, ca.v.weight], dim=0)),
-                "bkv_c": f32(torch.cat([ca.k.bias, ca.v.bias])), "nk_c": f32(ca.norm_k.weight),
                 "wo_c": bf(ca.o.weight), "bo_c": f32(ca.o.bias),
                 "w1": bf(b.ffn[0].weight), "b1": f32(b.ffn[0].bias),
                 "w2": bf(b.ffn[2].weight), "b2": f32(b.ffn[2].bias),
             }
             if getattr(b.norm3, "weight", None) is not None:
                 d["n3w"], d["n3b"] = f32(b.norm3.weight), f32(b.norm3.bias)
-            if self.family == "wan":
-                d["wkv_i"] = bf(torch.cat([ca.k_img.weight, ca.v_img.weight], dim=0))
-                d["bkv_i"] = f32(torch.cat([ca.k_img.bias, ca.v_img.bias]))
-                d["nk_i"] = f32(ca.norm_k_img.weight)
             blocks.append(d)
         P["blocks"] = blocks
+        # cross-attention K / V projections of ALL blocks as one weight: the conditioning tokens are the same for every block,
+        # so one [n_ctx, C] x [2*nb*C, C]^T GEMM (K rows of all blocks first, then V rows) replaces nb launches whose 128-wide
+        # tiles each took a full K loop's latency; same products, same rounding. +2*nb*C*C bf16 of HBM (5B: 1.1 GB).
+        cas = [b.cross_attn for b in m.blocks]
+        P["wkv_c"] = bf(torch.cat([ca.k.weight for ca in cas] + [ca.v.weight for ca in cas], dim=0))
+        P["bkv_c"] = f32(torch.cat([ca.k.bias for ca in cas] + [ca.v.bias for ca in cas]))
+        P["nk_c"] = f32(torch.stack([ca.norm_k.weight for ca in cas]))
+        if self.family == "wan":
+            P["wkv_i"] = bf(torch.cat([ca.k_img.weight for ca in cas] + [ca.v_img.weight for ca in cas], dim=0))
+            P["bkv_i"] = f32(torch.cat([ca.k_img.bias for ca in cas] + [ca.v_img.bias for ca in cas]))
+            P["nk_i"] = f32(torch.stack([ca.norm_k_img.weight for ca in cas]))
         P["mod_all"] = f32(torch.cat([b.modulation.reshape(1, 6 * C) for b in m.blocks], dim=0))
         P["mod_head"] = f32(m.head.modulation.reshape(2, C))
         wh = m.head.head.weight.detach().float()
@@ -219,18 +224,16 @@ class DiTEngine:
         ops.gemm_bf16(h, w3, b3, y, EPI_F32)
         ops.adaln_modulate(y, l4w, l4b, 0, None, False, out_rows, 0, eps=1e-5)
 
-    def _cross(self, hc, ctx_rows, nk, wkv, bkv, nk_w, ac, L, accumulate, blk, fresh):
-        """one cross-attention over ctx_rows (bf16 [nk, C]); result into ac (bf16 [L, C]). With cache_context the
-        projected K / V^T live in per-block buffers and are recomputed only when the conditioning changed."""
-        C, H = self.model.dim, self.model.num_heads
-        eps = self.model.eps
-        tag = f"{nk}_{blk}" if self.cache_context else f"{nk}"
-        kc = self._buf(f"kc_{tag}", (nk, C), torch.bfloat16)
-        vct = self._buf(f"vct_{tag}", (C, _round_up(nk, 8)), torch.bfloat16)
+    def _cross_kv(self, tag, ctx_rows, nk, wkv, bkv, nk_w, fresh):
+        """K (RMS-normalised) and K-major V^T of all blocks for one conditioning stream: kc [nk, nb*C], vct [nb*C, nk8].
+        Recomputed only when `fresh` (always, unless cache_context found the same conditioning tensors)."""
+        C, nb = self.model.dim, len(self.P["blocks"])
+        kc = self._buf(f"kc_{tag}_{nk}", (nk, nb * C), torch.bfloat16)
+        vct = self._buf(f"vct_{tag}_{nk}", (nb * C, _round_up(nk, 8)), torch.bfloat16)
         if fresh:
-            ops.gemm_bf16(ctx_rows, wkv, bkv, kc, EPI_BF16_SPLITT, out_t=vct, n_split=C)
-            ops.rmsnorm_rope(kc, C, 1, nk_w, eps)
-        ops.attn_fwd(hc, kc, vct, ac, L, nk, H, accumulate=accumulate)
+            ops.gemm_bf16(ctx_rows, wkv, bkv, kc, EPI_BF16_SPLITT, out_t=vct, n_split=nb * C)
+            ops.rmsnorm_rows_periodic(kc.view(nk * nb, C), C, nk_w, self.model.eps)
+        return kc, vct
 
     def _blocks(self, xs, L, tab, row_idx, R, rope, n_rope, ctx, n_img, ctx_fresh=True, n_keys=None):
         """xs fp32 [L, C] in/out. tab fp32 [nb, R, 6, C]; rope fp32 [n_rope, 64, 2] (n_rope == L here).
@@ -244,6 +247,10 @@ class DiTEngine:
         att = self._buf("att", (L, C), torch.bfloat16)
         ff = self._buf("ff", (L, Fd), torch.bfloat16)
         ts = 6 * C  # table row stride
+        ntxt = ctx.shape[0] - n_img
+        kc_t, vct_t = self._cross_kv("t", ctx[n_img:], ntxt, self.P["wkv_c"], self.P["bkv_c"], self.P["nk_c"], ctx_fresh)
+        if n_img:
+            kc_i, vct_i = self._cross_kv("i", ctx[:n_img], n_img, self.P["wkv_i"], self.P["bkv_i"], self.P["nk_i"], ctx_fresh)
         for i, d in enumerate(self.P["blocks"]):
             tb = tab[i]                      # [R, 6, C]
             shift_sa, scale_sa, gate_sa = tb[:, 0], tb[:, 1], tb[:, 2]
@@ -272,10 +279,9 @@ class DiTEngine:
                 ops.cast_bf16(xs, L, h)
             ops.gemm_bf16(h, d["wq_c"], d["bq_c"], qk[:, :C], EPI_BF16)
             ops.rmsnorm_rope(qk[:, :C], C, 1, d["nq_c"], eps)
-            ntxt = ctx.shape[0] - n_img
-            self._cross(qk[:, :C], ctx[n_img:], ntxt, d["wkv_c"], d["bkv_c"], d["nk_c"], att, L, False, i, ctx_fresh)
+            ops.attn_fwd(qk[:, :C], kc_t[:, i * C:(i + 1) * C], vct_t[i * C:(i + 1) * C], att, L, ntxt, H)
             if n_img:
-                self._cross(qk[:, :C], ctx[:n_img], n_img, d["wkv_i"], d["bkv_i"], d["nk_i"], att, L, True, i, ctx_fresh)
+                ops.attn_fwd(qk[:, :C], kc_i[:, i * C:(i + 1) * C], vct_i[i * C:(i + 1) * C], att, L, n_img, H, accumulate=True)
             ops.gemm_bf16(att, d["wo_c"], d["bo_c"], xs, EPI_RESID)
             # --- FFN
             ops.adaln_modulate(xs, scale_ff, shift_ff, ts, row_idx, True, h, 0, eps)

@@ -112,6 +112,16 @@ def rmsnorm_rope(buf, C, nparts, w, eps=1e-6, rope=None, head_dim=128):
     return buf
 
 
+def rmsnorm_rows_periodic(buf, C, w, eps=1e-6):
+    """in-place RMSNorm over C of bf16 `buf` [T, C]; row t uses weight row t % w.shape[0] (w fp32 [period, C])."""
+    lib = _lib.load()
+    _dev(buf, "buf", torch.bfloat16)
+    bp, ld = _rows(buf, "buf")
+    rc = lib.yume_rmsnorm_rows_periodic(bp, ld, buf.shape[0], C, w.data_ptr(), w.shape[0], eps, _stream())
+    _lib.check(rc, "yume_rmsnorm_rows_periodic")
+    return buf
+
+
 def attn_fwd(q, k, vt, out, Lq, Lk, H, scale=None, accumulate=False, variant=0):
     """out[Lq, H*128] = softmax(q k^T * scale) v ; q,k token-major bf16 2-D views, vt K-major [H*128, >=Lk]."""
     lib = _lib.load()
