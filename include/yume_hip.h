@@ -80,6 +80,9 @@ int yume_adaln_modulate(const float* x, int64_t ldx, int64_t T, int64_t C, float
  *                      (row stride ldt >= M) — the K-major V^T image the attention kernel consumes.
  *                      n_split must be a multiple of 128.
  * bias: fp32 [N] or NULL.
+ * variant: 0 = automatic — the 256x256-tile kernel once its tiles fill the chip, else the 128x128-tile kernel; when the
+ *   256x256 tiling would leave a last round of tiles at most ~1/3 full, whole rounds of M-tiles go to the 256x256 kernel and
+ *   the remaining rows to the 128x128 kernel (two launches inside this call). 1 = 128x128 kernel, 2 = 256x256 kernel.
  */
 enum {
     YUME_EPI_BF16 = 0,
