@@ -135,6 +135,13 @@ int yume_rmsnorm_rows_periodic(void* buf, int64_t ld, int64_t T, int64_t C, cons
 int yume_attn_fwd(const void* Q, int64_t ldq, const void* K, int64_t ldk, const void* Vt, int64_t ldvt,
                   void* O, int64_t ldo, int64_t Lq, int64_t Lk, int64_t H, float scale,
                   int accumulate, int variant, void* stream);
+/* Same call with caller-owned scratch (yume_attn_workspace_bytes(Lq, Lk, H) bytes, 0 = none needed; 16-byte aligned): in the
+ * automatic mode the query rows left to the 4-wave kernel are then computed as TWO key-range halves per workgroup (fp32 partial
+ * O, running max and row sum in the scratch) merged in a fixed order, so that two workgroups share a CU there as well. */
+int64_t yume_attn_workspace_bytes(int64_t Lq, int64_t Lk, int64_t H);
+int yume_attn_fwd_ws(const void* Q, int64_t ldq, const void* K, int64_t ldk, const void* Vt, int64_t ldvt,
+                     void* O, int64_t ldo, int64_t Lq, int64_t Lk, int64_t H, float scale,
+                     int accumulate, int variant, void* workspace, int64_t workspace_bytes, void* stream);
 
 /* ---- small-M fp32 linear (time embedding MLP) ---------------------------------------------
  * replaces: wan23/modules/model.py:459-461,803-812 (time_embedding, time_projection under

@@ -230,6 +230,16 @@ def test_attention_auto_splits_query_range_between_kernels():
         got = run_attn(q.view(Lq, H, 128), k.view(Lk, H, 128), v.view(Lk, H, 128), accumulate=base.clone() if acc else None, variant=0)
         assert rel_l2(got.float(), want.float()) < 2e-3
         assert (got.float() - want.float()).abs().max() <= 2.0 ** -6 * want.float().abs().max()
+    # the tail rows went through the key-range split (two partial softmaxes merged): same function as the unsplit call
+    qd, kd = q.to(DEV), k.to(DEV)
+    vt = torch.zeros(H * 128, Lk, dtype=torch.bfloat16, device=DEV)
+    ops.transpose_bf16(v.to(DEV), vt)
+    o_ws = torch.empty(Lq, H * 128, dtype=torch.bfloat16, device=DEV)
+    o_no = torch.empty_like(o_ws)
+    ops.attn_fwd(qd, kd, vt, o_ws, Lq, Lk, H, use_workspace=True)
+    ops.attn_fwd(qd, kd, vt, o_no, Lq, Lk, H, use_workspace=False)
+    assert torch.equal(o_ws[:8192], o_no[:8192])
+    assert rel_l2(o_ws[8192:].float().cpu(), o_no[8192:].float().cpu()) < 4e-3      # two bf16 roundings of fp32 values that differ in the last bits
 
 
 def test_flash_attention_seam():

@@ -27,6 +27,8 @@ SIGNATURES = {
     "yume_rmsnorm_rows_periodic": [_P, _L, _L, _L, _P, _L, _F, _P],
     "yume_rmsnorm_rope": [_P, _L, _L, _L, _I, _P, _F, _P, _L, _P],
     "yume_attn_fwd": [_P, _L, _P, _L, _P, _L, _P, _L, _L, _L, _L, _F, _I, _I, _P],
+    "yume_attn_workspace_bytes": [_L, _L, _L],
+    "yume_attn_fwd_ws": [_P, _L, _P, _L, _P, _L, _P, _L, _L, _L, _L, _F, _I, _I, _P, _L, _P],
     "yume_linear_smallm_f32": [_P, _L, _L, _P, _I, _P, _L, _I, _I, _P, _P, _P],
     "yume_sinusoidal_embed": [_P, _P, _L, _L, _P, _P],
     "yume_modulation_table": [_P, _P, _L, _L, _L, _P, _P],
@@ -44,7 +46,7 @@ SIGNATURES = {
     "yume_frames_u8": [_P, _L, _L, _L, _L, _P, _P],
     "yume_vae_unpack_output": [_P, _L, _L, _L, _L, _L, _I, _P, _P, _F, _F, _P, _P],
 }
-_RES = {"yume_last_error": c_char_p, "yume_target_arch": c_char_p, "yume_gemm_splitk_workspace_bytes": c_int64}
+_RES = {"yume_last_error": c_char_p, "yume_target_arch": c_char_p, "yume_gemm_splitk_workspace_bytes": c_int64, "yume_attn_workspace_bytes": c_int64}
 
 _lib = None
 

@@ -56,6 +56,10 @@ struct AttnArgs {
     int accumulate;
     int nqb;           // query blocks per head (of the rows [q_lo, Lq) this launch covers)
     int q_lo;          // first query row of this launch
+    // key-range split (gridDim.y = splits > 1, v2 kernel only): split s walks key tiles [nt*s/splits, nt*(s+1)/splits) and writes
+    // its UNNORMALISED O (fp32) + running max + row sum here; attn_combine_kernel merges the splits
+    float* part_o;     // [splits, Lq - q_lo, H*128]
+    float* part_ml;    // [splits, Lq - q_lo, H, 2]
 };
 
 struct Stage {
@@ -494,9 +498,18 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel_v2(AttnArgs p) {
 
     const int nt = (p.Lk + KT - 1) / KT;
     const bool ragged = (p.Lk % KT) != 0;          // then the LAST tile takes the register path
-    if (nt == 1 && ragged) {
+    const int nsp = gridDim.y, sp = blockIdx.y;    // key-range split (1 split = the whole range)
+    const int t0 = (int)((int64_t)nt * sp / nsp), t1 = (int)((int64_t)nt * (sp + 1) / nsp);
+    if (t0 > 0) {
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            dp.k[rr] += (int64_t)t0 * kstep;
+            dp.v[rr] += (int64_t)t0 * KT;
+        }
+    }
+    if (t0 == nt - 1 && ragged) {
         Stage st;
-        stage_load(st, p, h, 0, tid);
+        stage_load(st, p, h, t0 * KT, tid);
         stage_store_v2(st, smem, tid);
     } else {
         dma_tile(dp, kstep, smem, wave);
@@ -505,13 +518,13 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel_v2(AttnArgs p) {
     __syncthreads();
 
     int cur = 0;
-    for (int t = 0; t < nt; ++t) {
+    for (int t = t0; t < t1; ++t) {
         char* kb = smem + cur * V2_BUF;
         char* nb = smem + (cur ^ 1) * V2_BUF;
-        const bool has_next = t + 1 < nt;
+        const bool has_next = t + 1 < t1;
         const bool next_reg = has_next && ragged && (t + 2 == nt);
         if (has_next && !next_reg) dma_tile(dp, kstep, nb, wave);
-        if (!has_next && ragged)
+        if (t == nt - 1 && ragged)
             tile_body_v2<true>(kb, p, qf, oacc, m_run, l_run, t * KT, ql, hi, koff, voff);
         else
             tile_body_v2<false>(kb, p, qf, oacc, m_run, l_run, t * KT, ql, hi, koff, voff);
@@ -523,6 +536,27 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel_v2(AttnArgs p) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         cur ^= 1;
+    }
+
+    if (nsp > 1) {            // partial result of this key range
+        const float l_part = xhalf_sum(l_run);
+        const int q = q0 + ql;
+        if (q < p.Lq) {
+            const int64_t rows = p.Lq - p.q_lo, r = q - p.q_lo;
+            float* po = p.part_o + ((int64_t)sp * rows + r) * ((int64_t)p.H * D) + h * D + 4 * hi;
+#pragma unroll
+            for (int db = 0; db < 4; ++db)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    *reinterpret_cast<f32x4*>(po + 32 * db + 8 * g) =
+                        f32x4{oacc[db][4 * g + 0], oacc[db][4 * g + 1], oacc[db][4 * g + 2], oacc[db][4 * g + 3]};
+            if (hi == 0) {
+                float* pm = p.part_ml + (((int64_t)sp * rows + r) * p.H + h) * 2;
+                pm[0] = m_run;
+                pm[1] = l_part;
+            }
+        }
+        return;
     }
 
     const float l_tot = xhalf_sum(l_run);
@@ -905,12 +939,75 @@ __global__ __launch_bounds__(NW4 * 64, 2) void attn_fwd_kernel_v4(AttnArgs p) {
     }
 }
 
+
+// merge the key-range splits of the v2 kernel: O = sum_s O_s 2^(m_s - m) / sum_s l_s 2^(m_s - m), m = max_s m_s (fixed order)
+__global__ __launch_bounds__(256) void attn_combine_kernel(const float* __restrict__ part_o, const float* __restrict__ part_ml, int splits,
+                                                           int64_t rows, int H, unsigned short* __restrict__ O, int64_t ldo, int q_lo,
+                                                           int accumulate) {
+    const int64_t nq = rows * H * (D / 4);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nq; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % (D / 4));
+        const int h = (int)((i / (D / 4)) % H);
+        const int64_t r = i / ((int64_t)(D / 4) * H);
+        float m = NEG_BIG;
+        for (int s = 0; s < splits; ++s) m = fmaxf(m, part_ml[((s * rows + r) * H + h) * 2]);
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        float l = 0.f;
+        for (int s = 0; s < splits; ++s) {
+            const float* ml = part_ml + ((s * rows + r) * H + h) * 2;
+            const float a = __builtin_amdgcn_exp2f(ml[0] - m);
+            l += ml[1] * a;
+            acc += *reinterpret_cast<const f32x4*>(part_o + (s * rows + r) * ((int64_t)H * D) + h * D + 4 * c4) * a;
+        }
+        const float inv = 1.0f / l;
+        float v0 = acc[0] * inv, v1 = acc[1] * inv, v2 = acc[2] * inv, v3 = acc[3] * inv;
+        u32x2* dst = reinterpret_cast<u32x2*>(O + (q_lo + r) * ldo + h * D + 4 * c4);
+        if (accumulate) {
+            const u32x2 old = *dst;
+            v0 += bf16_to_f32((unsigned short)(old[0] & 0xffffu));
+            v1 += bf16_to_f32((unsigned short)(old[0] >> 16));
+            v2 += bf16_to_f32((unsigned short)(old[1] & 0xffffu));
+            v3 += bf16_to_f32((unsigned short)(old[1] >> 16));
+        }
+        u32x2 o;
+        o[0] = pack_bf16x2(v0, v1);
+        o[1] = pack_bf16x2(v2, v3);
+        *dst = o;
+    }
+}
+
 }  // namespace
 
+
+// query rows the automatic selection leaves to the 4-wave kernel after whole rounds of 8-wave workgroups (0: none / not applicable)
+static int64_t attn_tail_start(int64_t Lq, int64_t Lk, int64_t H) {
+    if (Lk < 1536 || Lq < QB4) return -1;
+    const int64_t hx = (H + 7) / 8, nq4 = (Lq + QB4 - 1) / QB4;
+    const int64_t nb = hx * nq4, R = nb / 32, r = nb % 32;
+    const int64_t nq_main = R >= 1 ? (32 * R) / hx : 0;
+    if (r > 0 && r <= 20 && nq_main >= 1 && nq_main < nq4) return nq_main * QB4;
+    return -1;
+}
+
+extern "C" int64_t yume_attn_workspace_bytes(int64_t Lq, int64_t Lk, int64_t H) {
+    const int64_t start = attn_tail_start(Lq, Lk, H);
+    if (start < 0) return 0;
+    return 2 * (Lq - start) * (H * D + H * 2) * 4;
+}
+
+extern "C" int yume_attn_fwd_ws(const void* Q, int64_t ldq, const void* K, int64_t ldk, const void* Vt, int64_t ldvt,
+                                void* O, int64_t ldo, int64_t Lq, int64_t Lk, int64_t H, float scale, int accumulate,
+                                int variant, void* workspace, int64_t workspace_bytes, void* stream);
 
 extern "C" int yume_attn_fwd(const void* Q, int64_t ldq, const void* K, int64_t ldk, const void* Vt, int64_t ldvt,
                              void* O, int64_t ldo, int64_t Lq, int64_t Lk, int64_t H, float scale, int accumulate,
                              int variant, void* stream) {
+    return yume_attn_fwd_ws(Q, ldq, K, ldk, Vt, ldvt, O, ldo, Lq, Lk, H, scale, accumulate, variant, nullptr, 0, stream);
+}
+
+extern "C" int yume_attn_fwd_ws(const void* Q, int64_t ldq, const void* K, int64_t ldk, const void* Vt, int64_t ldvt,
+                                void* O, int64_t ldo, int64_t Lq, int64_t Lk, int64_t H, float scale, int accumulate,
+                                int variant, void* workspace, int64_t workspace_bytes, void* stream) {
     YUME_REQUIRE(Q && K && Vt && O, "attn_fwd: NULL pointer");
     YUME_REQUIRE(Lq > 0 && Lk > 0 && H > 0, "attn_fwd: empty problem Lq=%lld Lk=%lld H=%lld", (long long)Lq, (long long)Lk, (long long)H);
     YUME_REQUIRE(Lq < (1ll << 30) && Lk < (1ll << 30) && H < 65536, "attn_fwd: dimension too large");
@@ -927,6 +1024,8 @@ extern "C" int yume_attn_fwd(const void* Q, int64_t ldq, const void* K, int64_t 
     a.accumulate = accumulate;
     a.q_lo = 0;
     a.nqb = 0;
+    a.part_o = nullptr;
+    a.part_ml = nullptr;
     hipStream_t st = (hipStream_t)stream;
     // launch one kernel over the query rows [lo, hi)
     auto run = [&](int kernel, int64_t lo, int64_t hi) {
@@ -957,7 +1056,24 @@ extern "C" int yume_attn_fwd(const void* Q, int64_t ldq, const void* K, int64_t 
         const int64_t nq_main = R >= 1 ? (32 * R) / hx : 0;
         if (r > 0 && r <= 20 && nq_main >= 1 && nq_main < nq4) {
             run(4, 0, nq_main * QB4);
-            run(2, nq_main * QB4, Lq);
+            const int64_t lo = nq_main * QB4, rows = Lq - lo;
+            const int64_t need = 2 * rows * (H * D + H * 2) * 4;
+            const int64_t tail_blocks = hx * ((rows + QB - 1) / QB);
+            if (workspace && workspace_bytes >= need && tail_blocks <= 32 && Lk >= 4 * KT) {
+                // the tail is at most one 4-wave workgroup per CU: cut its key range in two so that two workgroups share a CU
+                // (as in the kernel's normal operating point) and each walks half the keys; merged in a fixed order
+                AttnArgs b = a;
+                b.q_lo = (int)lo;
+                b.nqb = (int)((rows + QB - 1) / QB);
+                b.part_o = reinterpret_cast<float*>(workspace);
+                b.part_ml = b.part_o + 2 * rows * H * D;
+                hipLaunchKernelGGL(attn_fwd_kernel_v2, dim3((unsigned)(hx * b.nqb * 8), 2), dim3(NW * 64), 0, st, b);
+                const int64_t nq = rows * H * (D / 4);
+                hipLaunchKernelGGL(attn_combine_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, st, b.part_o, b.part_ml, 2,
+                                   rows, (int)H, (unsigned short*)O, ldo, (int)lo, accumulate);
+            } else {
+                run(2, lo, Lq);
+            }
         } else {
             run(4, 0, Lq);
         }

@@ -122,7 +122,10 @@ def rmsnorm_rows_periodic(buf, C, w, eps=1e-6):
     return buf
 
 
-def attn_fwd(q, k, vt, out, Lq, Lk, H, scale=None, accumulate=False, variant=0):
+_attn_ws, _attn_ws_bytes = {}, {}
+
+
+def attn_fwd(q, k, vt, out, Lq, Lk, H, scale=None, accumulate=False, variant=0, use_workspace=True):
     """out[Lq, H*128] = softmax(q k^T * scale) v ; q,k token-major bf16 2-D views, vt K-major [H*128, >=Lk]."""
     lib = _lib.load()
     _dev(q, "q", torch.bfloat16)
@@ -135,8 +138,18 @@ def attn_fwd(q, k, vt, out, Lq, Lk, H, scale=None, accumulate=False, variant=0):
     op, ldo = _rows(out, "out")
     if scale is None:
         scale = 1.0 / math.sqrt(128.0)
-    rc = lib.yume_attn_fwd(qp, ldq, kp, ldk, vp, ldv, op, ldo, Lq, Lk, H, scale, 1 if accumulate else 0, variant,
-                           _stream())
+    ws, nbytes = None, 0
+    if variant == 0 and use_workspace:
+        key = (q.device.index, Lq, Lk, H)
+        nbytes = _attn_ws_bytes.get(key)
+        if nbytes is None:
+            nbytes = _attn_ws_bytes[key] = int(lib.yume_attn_workspace_bytes(Lq, Lk, H))
+        if nbytes:
+            ws = _attn_ws.get(q.device.index)
+            if ws is None or ws.numel() < nbytes:
+                ws = _attn_ws[q.device.index] = torch.empty(nbytes, dtype=torch.uint8, device=q.device)
+    rc = lib.yume_attn_fwd_ws(qp, ldq, kp, ldk, vp, ldv, op, ldo, Lq, Lk, H, scale, 1 if accumulate else 0, variant,
+                              _ptr(ws), nbytes if ws is not None else 0, _stream())
     _lib.check(rc, "yume_attn_fwd")
     return out
 
