@@ -261,3 +261,12 @@ def test_sequence_parallel_two_ranks_match_single_rank(name, tmp_path):
     assert outs[0].shape == single.shape
     assert rel_l2(outs[0], single) < 2e-3, rel_l2(outs[0], single)
     assert rel_l2(outs[0], fx["out"]) <= 1.5e-2
+
+
+def test_end_to_end_example_runs_small():
+    """examples/sample_5b_synthetic.py --small: ids -> umT5 -> VAE encode -> FramePack chunks on the DiT -> VAE decode -> uint8."""
+    import subprocess
+    r = subprocess.run([sys.executable, f"{ROOT}/examples/sample_5b_synthetic.py", "--small", "--chunks", "2", "--steps", "3"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "uint8 frames on the host: (1, 58, 64, 96, 3)" in r.stdout
