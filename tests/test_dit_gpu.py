@@ -270,3 +270,8 @@ def test_end_to_end_example_runs_small():
                        capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "uint8 frames on the host: (1, 58, 64, 96, 3)" in r.stdout
+    # 14B flavour: CLIP vision tower + Wan2.1 VAE + umT5 (prompt / negative prompt) + CFG steps with re-noised history
+    r = subprocess.run([sys.executable, f"{ROOT}/examples/sample_14b_synthetic.py", "--small", "--steps", "3"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "uint8 frames (1, 65, 64, 96, 3)" in r.stdout
