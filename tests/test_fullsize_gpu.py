@@ -223,3 +223,32 @@ def test_full_resolution_wan21_decoder_is_causal():
     # not bit-equal: the 1x1x1 conv on all T latents at once is a plain GEMM whose kernel choice (256x256 rounds + 128x128
     # remainder rows) depends on T; the two tilings differ in the last fp32 bits, which the bf16 activations then amplify
     assert rel_l2(head, full[:, :13]) < 2e-3 and (head - full[:, :13]).abs().max() < 5e-2
+
+
+def test_full_5b_engine_two_independent_kernel_sets_agree():
+    """All 30 blocks at L = 9460 on the product kernels (256x256 GEMM + row split, 8-wave attention + splits) against the same
+    engine forced onto the independent kernels (128x128-tile GEMM, register-staged 4-wave attention): two implementations of
+    every hot product, same bf16 operand rounding points, different tilings / schedules / summation orders."""
+    from yume_amd import framepack
+    from yume_amd.wan23.modules.model import WanModel
+    cfg = dict(synth.CFG_5B)
+    with torch.device(DEV):
+        model = WanModel(**cfg)
+    synth.randomize_module_(model, seed=6)
+    model = model.to(torch.bfloat16).eval().requires_grad_(False)
+    F, H, W, lfz = 13, 44, 80, 8
+    plan = framepack.pack_plan(F, H, W, lfz)
+    g = torch.Generator(device=DEV).manual_seed(3)
+    x = torch.randn(48, F, H, W, device=DEV, generator=g)
+    ctx = torch.randn(77, 4096, device=DEV, generator=g)
+    t = torch.cat([torch.zeros(plan.n_hist_tok), torch.full((plan.n_new_tok,), 450.0)]).unsqueeze(0).to(DEV)
+
+    def run():
+        return model([x], t=t, context=[ctx], seq_len=plan.seq_len, latent_frame_zero=lfz, flag=True)[0]
+    prod = run()
+    model.engine.gemm_variant, model.engine.attn_variant = 1, 1
+    alt = run()
+    model.engine.gemm_variant, model.engine.attn_variant = 0, 0
+    e = rel_l2(prod, alt)
+    print(f"full 5B, 30 blocks: product kernels vs independent kernels rel-L2 {e:.3e}")
+    assert torch.isfinite(prod).all() and e <= 1e-2

@@ -41,6 +41,10 @@ class DiTEngine:
         # conditioning, not on the latent or the timestep; with cache_context they are computed once per conditioning
         # tensor (same object, same version) instead of once per denoise step. Off by default = the reference's work.
         self.cache_context = False
+        # kernel selection passed to every GEMM / attention call: 0 = automatic (product setting); tests set (1, 1) to run the
+        # whole model on the independent 128x128-tile GEMM and register-staged attention kernels as a cross-check
+        self.gemm_variant = 0
+        self.attn_variant = 0
         # a yume_amd.ulysses.SequenceParallel splits ONE chain's tokens over the ranks of its group
         self.sp = None
         self._ctx_key = None
@@ -162,7 +166,7 @@ class DiTEngine:
             a = self._buf("pe_a5", (g.nf * h4 * w4, w.shape[1]), torch.bfloat16)
             ops.patch_gather(u, g.f0, g.nf, 4, 4, a)
             mid = self._buf("pe_mid", (g.nf * h4 * w4, Cin), torch.float32)
-            ops.gemm_bf16(a, w, b, mid, EPI_F32)
+            ops.gemm_bf16(a, w, b, mid, EPI_F32, variant=self.gemm_variant)
             # layout change only: token-major [f,h,w,c] -> [c,f,h,w] for the second gather
             u = mid.view(g.nf, h4, w4, Cin).permute(3, 0, 1, 2).contiguous()
             f0, lvl = 0, 4
@@ -175,7 +179,7 @@ class DiTEngine:
         k = 2 << lvl
         a = self._buf(f"pe_a{lvl}_{g.ntok}", (g.ntok, w.shape[1]), torch.bfloat16)
         ops.patch_gather(u, f0, g.nf, k, k, a)
-        ops.gemm_bf16(a, w, b, xs_rows, EPI_F32)
+        ops.gemm_bf16(a, w, b, xs_rows, EPI_F32, variant=self.gemm_variant)
 
     def _time_rows(self, t64, t_index, R):
         """e [R, C], e0 [R, 6C] for the R distinct timesteps (fp32 islands of the reference)."""
@@ -208,8 +212,8 @@ class DiTEngine:
         else:
             cpad.zero_()                       # empty prompt: the reference pads [0, text_dim] to text_len zero rows (model.py:816-821)
         hid = self._buf("ctx_hid", (m.text_len, m.dim), torch.bfloat16)
-        ops.gemm_bf16(cpad, w0, b0, hid, EPI_BF16_GELU)
-        ops.gemm_bf16(hid, w2, b2, out_rows, EPI_BF16)
+        ops.gemm_bf16(cpad, w0, b0, hid, EPI_BF16_GELU, variant=self.gemm_variant)
+        ops.gemm_bf16(hid, w2, b2, out_rows, EPI_BF16, variant=self.gemm_variant)
 
     def _img_ctx(self, clip_fea, out_rows):
         C = self.model.dim
@@ -219,9 +223,9 @@ class DiTEngine:
         a = self._buf("img_a", (n, d), torch.bfloat16)
         ops.adaln_modulate(x, lw, lb, 0, None, False, a, 0, eps=1e-5)         # nn.LayerNorm default eps
         h = self._buf("img_h", (n, d), torch.bfloat16)
-        ops.gemm_bf16(a, w1, b1, h, EPI_BF16_GELU_ERF)
+        ops.gemm_bf16(a, w1, b1, h, EPI_BF16_GELU_ERF, variant=self.gemm_variant)
         y = self._buf("img_y", (n, C), torch.float32)
-        ops.gemm_bf16(h, w3, b3, y, EPI_F32)
+        ops.gemm_bf16(h, w3, b3, y, EPI_F32, variant=self.gemm_variant)
         ops.adaln_modulate(y, l4w, l4b, 0, None, False, out_rows, 0, eps=1e-5)
 
     def _cross_kv(self, tag, ctx_rows, nk, wkv, bkv, nk_w, fresh):
@@ -231,7 +235,7 @@ class DiTEngine:
         kc = self._buf(f"kc_{tag}_{nk}", (nk, nb * C), torch.bfloat16)
         vct = self._buf(f"vct_{tag}_{nk}", (nb * C, _round_up(nk, 8)), torch.bfloat16)
         if fresh:
-            ops.gemm_bf16(ctx_rows, wkv, bkv, kc, EPI_BF16_SPLITT, out_t=vct, n_split=nb * C)
+            ops.gemm_bf16(ctx_rows, wkv, bkv, kc, EPI_BF16_SPLITT, out_t=vct, n_split=nb * C, variant=self.gemm_variant)
             ops.rmsnorm_rows_periodic(kc.view(nk * nb, C), C, nk_w, self.model.eps)
         return kc, vct
 
@@ -257,42 +261,42 @@ class DiTEngine:
             shift_ff, scale_ff, gate_ff = tb[:, 3], tb[:, 4], tb[:, 5]
             # --- self attention
             ops.adaln_modulate(xs, scale_sa, shift_sa, ts, row_idx, True, h, 0, eps)
-            ops.gemm_bf16(h, d["wqkv"], d["bqkv"], qk, EPI_BF16_SPLITT, out_t=vt, n_split=2 * C)
+            ops.gemm_bf16(h, d["wqkv"], d["bqkv"], qk, EPI_BF16_SPLITT, out_t=vt, n_split=2 * C, variant=self.gemm_variant)
             if n_rope == L:
                 ops.rmsnorm_rope(qk, C, 2, d["nqk"], eps, rope)
             else:
                 ops.rmsnorm_rope(qk[:n_rope], C, 2, d["nqk"], eps, rope)
                 ops.rmsnorm_rope(qk[n_rope:], C, 2, d["nqk"], eps, None)
             if self.sp is None:
-                ops.attn_fwd(qk[:, :C], qk[:, C:], vt, att, L, L, H)
+                ops.attn_fwd(qk[:, :C], qk[:, C:], vt, att, L, L, H, variant=self.attn_variant)
                 sa = att
             else:      # Ulysses: all tokens x this rank's heads, then back (2 collectives, yume_amd/ulysses.py)
                 qf, kf, vtf = self.sp.exchange_qkv(qk, vt, C)
                 of = self._buf("att_sp", (qf.shape[0], qf.shape[1]), torch.bfloat16)
-                ops.attn_fwd(qf, kf, vtf, of, qf.shape[0], n_keys, H // self.sp.world)
+                ops.attn_fwd(qf, kf, vtf, of, qf.shape[0], n_keys, H // self.sp.world, variant=self.attn_variant)
                 sa = self.sp.exchange_out(of)
-            ops.gemm_bf16(sa, d["wo"], d["bo"], xs, EPI_RESID, gate=gate_sa, gate_stride=ts, row_idx=row_idx)
+            ops.gemm_bf16(sa, d["wo"], d["bo"], xs, EPI_RESID, gate=gate_sa, gate_stride=ts, row_idx=row_idx, variant=self.gemm_variant)
             # --- cross attention
             if "n3w" in d:
                 ops.adaln_modulate(xs, d["n3w"], d["n3b"], 0, None, False, h, 0, eps)
             else:
                 ops.cast_bf16(xs, L, h)
-            ops.gemm_bf16(h, d["wq_c"], d["bq_c"], qk[:, :C], EPI_BF16)
+            ops.gemm_bf16(h, d["wq_c"], d["bq_c"], qk[:, :C], EPI_BF16, variant=self.gemm_variant)
             ops.rmsnorm_rope(qk[:, :C], C, 1, d["nq_c"], eps)
-            ops.attn_fwd(qk[:, :C], kc_t[:, i * C:(i + 1) * C], vct_t[i * C:(i + 1) * C], att, L, ntxt, H)
+            ops.attn_fwd(qk[:, :C], kc_t[:, i * C:(i + 1) * C], vct_t[i * C:(i + 1) * C], att, L, ntxt, H, variant=self.attn_variant)
             if n_img:
-                ops.attn_fwd(qk[:, :C], kc_i[:, i * C:(i + 1) * C], vct_i[i * C:(i + 1) * C], att, L, n_img, H, accumulate=True)
-            ops.gemm_bf16(att, d["wo_c"], d["bo_c"], xs, EPI_RESID)
+                ops.attn_fwd(qk[:, :C], kc_i[:, i * C:(i + 1) * C], vct_i[i * C:(i + 1) * C], att, L, n_img, H, accumulate=True, variant=self.attn_variant)
+            ops.gemm_bf16(att, d["wo_c"], d["bo_c"], xs, EPI_RESID, variant=self.gemm_variant)
             # --- FFN
             ops.adaln_modulate(xs, scale_ff, shift_ff, ts, row_idx, True, h, 0, eps)
             if self.prof is not None:     # bench.py: HIP events around the dominant kernel, same stream
                 ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
                 ev[0].record()
-            ops.gemm_bf16(h, d["w1"], d["b1"], ff, EPI_BF16_GELU)
+            ops.gemm_bf16(h, d["w1"], d["b1"], ff, EPI_BF16_GELU, variant=self.gemm_variant)
             if self.prof is not None:
                 ev[1].record()
                 self.prof.append(ev)
-            ops.gemm_bf16(ff, d["w2"], d["b2"], xs, EPI_RESID, gate=gate_ff, gate_stride=ts, row_idx=row_idx)
+            ops.gemm_bf16(ff, d["w2"], d["b2"], xs, EPI_RESID, gate=gate_ff, gate_stride=ts, row_idx=row_idx, variant=self.gemm_variant)
 
     def _head(self, xs_new, row_idx_new, e, R, grid):
         """xs_new fp32 [Ln, C] -> fp32 [Cout, F, 2*Hp, 2*Wp]."""
@@ -316,7 +320,7 @@ class DiTEngine:
         a3 = self._buf("head_a", (Ln, 3 * C), torch.bfloat16)
         ops.adaln_modulate(xs_new, th[1], th[0], C, row_idx_new, True, a3, 2, m.eps)
         y = self._buf("head_y", (Ln, 4 * Co), torch.float32)
-        ops.gemm_bf16(a3, self.P["whead"], self.P["bhead"], y, EPI_F32)
+        ops.gemm_bf16(a3, self.P["whead"], self.P["bhead"], y, EPI_F32, variant=self.gemm_variant)
         return y
 
     # ------------------------------------------------------------------ one sample forward
