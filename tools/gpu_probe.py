@@ -35,7 +35,7 @@ def main():
     res = {"device": torch.cuda.get_device_name(0)}
     L, C, H, FF = 9460, 3072, 24, 14336
     bf = lambda *s: (torch.randn(*s, device=DEV) * 0.5).to(torch.bfloat16)
-    variants = [int(v) for v in os.environ.get("YUME_GEMM_VARIANTS", "1,2").split(",")]
+    variants = [int(v) for v in os.environ.get("YUME_GEMM_VARIANTS", "1,2,0").split(",")]
     # ---- GEMMs
     shapes = {"qkv": (L, 3 * C, C), "o": (L, C, C), "ffn1": (L, FF, C), "ffn2": (L, C, FF), "sq4096": (4096, 4096, 4096),
               "sq8192": (8192, 8192, 8192)}
@@ -71,7 +71,7 @@ def main():
         vtt = bf(Cc, (Lk + 7) // 8 * 8)
         o = torch.empty(Lq, Cc, dtype=torch.bfloat16, device=DEV)
         fl = 4 * Lq * Lk * Cc
-        for av in [int(v) for v in os.environ.get("YUME_ATTN_VARIANTS", "1,2,4").split(",")]:
+        for av in [int(v) for v in os.environ.get("YUME_ATTN_VARIANTS", "1,2,4,0").split(",")]:
             ms = timeit(lambda: ops.attn_fwd(q, k, vtt, o, Lq, Lk, Hh, variant=av), warm=1, iters=3)
             res[f"attn_{tag}_v{av}"] = {"ms": ms, "tflops": fl / ms / 1e9}
             print(f"attn {tag} v{av} Lq={Lq} Lk={Lk} H={Hh}: {ms:.3f} ms {fl/ms/1e9:.0f} TF", flush=True)
