@@ -1,0 +1,175 @@
+// attn_check — standalone (no torch) correctness + timing harness for yume_attn_fwd variants.
+//   build:  hipcc -O2 --offload-arch=gfx950 tools/attn_check.cpp -o tools/attn_check -Lyume_amd/lib -lyume_hip -Wl,-rpath,'$ORIGIN/../yume_amd/lib'
+//   run:    tools/attn_check [variants...]        (default variants: 7 4 2 0)
+// Small shapes are checked against an fp64 exact-softmax reference computed on the host (test infrastructure, like oracle/);
+// large shapes are checked against variant 2 (itself checked on the small shapes) and timed with HIP events.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+#include "../include/yume_hip.h"
+
+#define HC(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(2); } } while (0)
+
+static uint16_t f2bf(float f) {
+    uint32_t u; memcpy(&u, &f, 4);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+static float bf2f(uint16_t h) { uint32_t u = (uint32_t)h << 16; float f; memcpy(&f, &u, 4); return f; }
+static uint64_t rng_state = 0x9E3779B97F4A7C15ull;
+static float rnd() {   // ~N(0,1): sum of 4 uniforms
+    float s = 0;
+    for (int i = 0; i < 4; ++i) {
+        rng_state = rng_state * 6364136223846793005ull + 1442695040888963407ull;
+        s += (float)((rng_state >> 33) & 0xffffff) / 16777216.0f - 0.5f;
+    }
+    return s * 1.7320508f;
+}
+
+struct Prob {
+    int64_t Lq, Lk, H, ldq, ldk, ldvt, ldo;
+    std::vector<uint16_t> q, k, vt, o0;
+    uint16_t *dq, *dk, *dvt, *d_o;
+    void* ws; int64_t wsb;
+};
+
+static void make(Prob& p, int64_t Lq, int64_t Lk, int64_t H, int spike) {
+    p.Lq = Lq; p.Lk = Lk; p.H = H;
+    p.ldq = H * 128; p.ldk = H * 128; p.ldo = H * 128;
+    p.ldvt = (Lk + 7) / 8 * 8;
+    p.q.resize(Lq * p.ldq); p.k.resize(Lk * p.ldk); p.vt.assign(H * 128 * p.ldvt, 0x7fc0 /* NaN in the padding: must never leak */);
+    p.o0.resize(Lq * p.ldo);
+    for (auto& x : p.q) x = f2bf(rnd());
+    for (auto& x : p.k) x = f2bf(rnd());
+    for (int64_t r = 0; r < H * 128; ++r)
+        for (int64_t c = 0; c < Lk; ++c) p.vt[r * p.ldvt + c] = f2bf(rnd());
+    for (auto& x : p.o0) x = f2bf(rnd());
+    if (spike) {
+        // one key far above the rest for some queries, late in the sequence: forces the rescale / redo path in a late tile
+        int64_t key = Lk - 1 - (Lk > 70 ? 37 : 0);
+        for (int64_t h = 0; h < H; ++h)
+            for (int d = 0; d < 128; ++d) {
+                float qv = bf2f(p.q[(Lq / 2) * p.ldq + h * 128 + d]);
+                p.k[key * p.ldk + h * 128 + d] = f2bf(qv * 6.0f);
+            }
+    }
+    HC(hipMalloc(&p.dq, p.q.size() * 2)); HC(hipMalloc(&p.dk, p.k.size() * 2)); HC(hipMalloc(&p.dvt, p.vt.size() * 2)); HC(hipMalloc(&p.d_o, p.o0.size() * 2));
+    HC(hipMemcpy(p.dq, p.q.data(), p.q.size() * 2, hipMemcpyHostToDevice));
+    HC(hipMemcpy(p.dk, p.k.data(), p.k.size() * 2, hipMemcpyHostToDevice));
+    HC(hipMemcpy(p.dvt, p.vt.data(), p.vt.size() * 2, hipMemcpyHostToDevice));
+    p.wsb = yume_attn_workspace_bytes(Lq, Lk, H);
+    p.ws = nullptr;
+    if (p.wsb) HC(hipMalloc(&p.ws, p.wsb));
+}
+static void drop(Prob& p) { hipFree(p.dq); hipFree(p.dk); hipFree(p.dvt); hipFree(p.d_o); if (p.ws) hipFree(p.ws); }
+
+static int run(Prob& p, int variant, int accumulate, std::vector<uint16_t>& out) {
+    HC(hipMemcpy(p.d_o, p.o0.data(), p.o0.size() * 2, hipMemcpyHostToDevice));
+    int rc = yume_attn_fwd_ws(p.dq, p.ldq, p.dk, p.ldk, p.dvt, p.ldvt, p.d_o, p.ldo, p.Lq, p.Lk, p.H, 0.08838834764831845f, accumulate, variant,
+                              p.ws, p.wsb, nullptr);
+    if (rc) { printf("  variant %d: rc=%d %s\n", variant, rc, yume_last_error()); return rc; }
+    hipError_t e = hipDeviceSynchronize();
+    if (e != hipSuccess) { printf("  variant %d: device error %s\n", variant, hipGetErrorString(e)); exit(3); }
+    out.resize(p.o0.size());
+    HC(hipMemcpy(out.data(), p.d_o, out.size() * 2, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+static void reference(const Prob& p, int accumulate, std::vector<float>& ref) {
+    ref.assign(p.Lq * p.ldo, 0.f);
+    std::vector<double> s(p.Lk);
+    for (int64_t h = 0; h < p.H; ++h)
+        for (int64_t i = 0; i < p.Lq; ++i) {
+            double mx = -1e300;
+            for (int64_t j = 0; j < p.Lk; ++j) {
+                double a = 0;
+                for (int d = 0; d < 128; ++d) a += (double)bf2f(p.q[i * p.ldq + h * 128 + d]) * bf2f(p.k[j * p.ldk + h * 128 + d]);
+                s[j] = a * 0.08838834764831845;
+                mx = s[j] > mx ? s[j] : mx;
+            }
+            double l = 0;
+            for (int64_t j = 0; j < p.Lk; ++j) { s[j] = exp(s[j] - mx); l += s[j]; }
+            for (int d = 0; d < 128; ++d) {
+                double a = 0;
+                for (int64_t j = 0; j < p.Lk; ++j) a += s[j] * bf2f(p.vt[(h * 128 + d) * p.ldvt + j]);
+                a /= l;
+                if (accumulate) a += bf2f(p.o0[i * p.ldo + h * 128 + d]);
+                ref[i * p.ldo + h * 128 + d] = (float)a;
+            }
+        }
+}
+
+static double maxdiff(const std::vector<uint16_t>& a, const std::vector<float>& r, int* nan) {
+    double m = 0; *nan = 0;
+    for (size_t i = 0; i < a.size(); ++i) {
+        float x = bf2f(a[i]);
+        if (x != x) { ++*nan; continue; }
+        double d = fabs((double)x - r[i]);
+        m = d > m ? d : m;
+    }
+    return m;
+}
+static double maxdiff2(const std::vector<uint16_t>& a, const std::vector<uint16_t>& b, int* nan) {
+    double m = 0; *nan = 0;
+    for (size_t i = 0; i < a.size(); ++i) {
+        float x = bf2f(a[i]), y = bf2f(b[i]);
+        if (x != x || y != y) { ++*nan; continue; }
+        double d = fabs((double)x - y);
+        m = d > m ? d : m;
+    }
+    return m;
+}
+
+int main(int argc, char** argv) {
+    std::vector<int> variants;
+    for (int i = 1; i < argc; ++i) variants.push_back(atoi(argv[i]));
+    if (variants.empty()) variants = {7, 4, 2, 0};
+    int fails = 0;
+    const int small[][4] = {{256, 64, 1, 0}, {64, 40, 1, 0}, {1, 1, 1, 0}, {300, 200, 2, 0}, {273, 323, 3, 0}, {256, 256, 1, 0}, {256, 320, 1, 0},
+                            {513, 640, 9, 0}, {700, 1000, 8, 1}, {256, 577, 2, 1}, {260, 448, 1, 0}, {512, 512, 3, 1}, {384, 1999, 2, 1}};
+    for (auto& sh : small) {
+        for (int acc = 0; acc < 2; ++acc) {
+            Prob p; make(p, sh[0], sh[1], sh[2], sh[3]);
+            std::vector<float> ref; reference(p, acc, ref);
+            for (int v : variants) {
+                if ((v == 4) && (sh[0] < 1)) continue;
+                std::vector<uint16_t> out;
+                if (run(p, v, acc, out)) { ++fails; continue; }
+                int nan; double md = maxdiff(out, ref, &nan);
+                const bool ok = nan == 0 && md < (acc ? 6e-2 : 4e-2);
+                printf("small Lq=%d Lk=%d H=%d spike=%d acc=%d variant=%d  maxabs=%.3e nan=%d %s\n", sh[0], sh[1], sh[2], sh[3], acc, v, md, nan, ok ? "ok" : "FAIL");
+                if (!ok) ++fails;
+            }
+            drop(p);
+        }
+    }
+    const int big[][3] = {{9460, 9460, 24}, {8192, 9460, 24}, {2048, 4096, 16}, {23460, 23460, 40}};
+    for (auto& sh : big) {
+        Prob p; make(p, sh[0], sh[1], sh[2], 1);
+        std::vector<uint16_t> base;
+        if (run(p, 2, 0, base)) { ++fails; drop(p); continue; }
+        for (int v : variants) {
+            std::vector<uint16_t> out;
+            if (run(p, v, 0, out)) { ++fails; continue; }
+            int nan; double md = maxdiff2(out, base, &nan);
+            hipEvent_t e0, e1; HC(hipEventCreate(&e0)); HC(hipEventCreate(&e1));
+            const int it = sh[0] > 20000 ? 3 : 10;
+            for (int i = 0; i < 2; ++i) yume_attn_fwd_ws(p.dq, p.ldq, p.dk, p.ldk, p.dvt, p.ldvt, p.d_o, p.ldo, p.Lq, p.Lk, p.H, 0.0883883f, 0, v, p.ws, p.wsb, nullptr);
+            HC(hipEventRecord(e0, nullptr));
+            for (int i = 0; i < it; ++i) yume_attn_fwd_ws(p.dq, p.ldq, p.dk, p.ldk, p.dvt, p.ldvt, p.d_o, p.ldo, p.Lq, p.Lk, p.H, 0.0883883f, 0, v, p.ws, p.wsb, nullptr);
+            HC(hipEventRecord(e1, nullptr)); HC(hipEventSynchronize(e1));
+            float ms; HC(hipEventElapsedTime(&ms, e0, e1)); ms /= it;
+            const double tf = 4.0 * sh[0] * sh[1] * 128.0 * sh[2] / (ms * 1e-3) / 1e12;
+            const bool ok = nan == 0 && md < 3e-2;
+            printf("big Lq=%d Lk=%d H=%d variant=%d  vs v2 maxabs=%.3e nan=%d %s   %.3f ms  %.0f TFLOP/s\n", sh[0], sh[1], sh[2], v, md, nan, ok ? "ok" : "FAIL", ms, tf);
+            if (!ok) ++fails;
+        }
+        drop(p);
+    }
+    printf("attn_check: %d failure(s)\n", fails);
+    return fails ? 1 : 0;
+}

@@ -1,0 +1,23 @@
+// attn_args.hpp — launch arguments shared by the attention kernels (attn_fwd.hip, attn_fwd7.hip).
+#pragma once
+#include <stdint.h>
+#include <hip/hip_runtime.h>
+
+struct AttnArgs {
+    const unsigned short* Q; int64_t ldq;
+    const unsigned short* K; int64_t ldk;
+    const unsigned short* Vt; int64_t ldvt;
+    unsigned short* O; int64_t ldo;
+    int Lq, Lk, H;
+    float scale_log2;  // softmax scale * log2(e)
+    int accumulate;
+    int nqb;           // query blocks per head (of the rows [q_lo, Lq) this launch covers)
+    int q_lo;          // first query row of this launch
+    // key-range split (gridDim.y = splits > 1, v2 kernel only): split s walks key tiles [nt*s/splits, nt*(s+1)/splits) and writes
+    // its UNNORMALISED O (fp32) + running max + row sum here; attn_combine_kernel merges the splits
+    float* part_o;     // [splits, Lq - q_lo, H*128]
+    float* part_ml;    // [splits, Lq - q_lo, H, 2]
+};
+
+// attn_fwd7.hip: 4-wave / 64-queries-per-wave kernel (one wave per SIMD, 512 registers); grid = ceil(H/8) * nqb * 8 blocks
+void yume_attn7_launch(const AttnArgs& a, hipStream_t st);

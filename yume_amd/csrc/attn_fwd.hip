@@ -21,6 +21,7 @@
 //           chunk c ^ ((d >> 1) & 7), the swizzle applied on the SOURCE address of the LDS-DMA
 // Roofline: MFMA (bf16 dense). Algorithmic work 4*Lq*Lk*128 flop per head.
 #include "common.hpp"
+#include "attn_args.hpp"
 
 namespace {
 
@@ -45,22 +46,6 @@ __device__ __forceinline__ float xhalf_sum(float v) {
     const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
     return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
-
-struct AttnArgs {
-    const unsigned short* Q; int64_t ldq;
-    const unsigned short* K; int64_t ldk;
-    const unsigned short* Vt; int64_t ldvt;
-    unsigned short* O; int64_t ldo;
-    int Lq, Lk, H;
-    float scale_log2;  // softmax scale * log2(e)
-    int accumulate;
-    int nqb;           // query blocks per head (of the rows [q_lo, Lq) this launch covers)
-    int q_lo;          // first query row of this launch
-    // key-range split (gridDim.y = splits > 1, v2 kernel only): split s walks key tiles [nt*s/splits, nt*(s+1)/splits) and writes
-    // its UNNORMALISED O (fp32) + running max + row sum here; attn_combine_kernel merges the splits
-    float* part_o;     // [splits, Lq - q_lo, H*128]
-    float* part_ml;    // [splits, Lq - q_lo, H, 2]
-};
 
 struct Stage {
     u32x4 k[4];
@@ -1032,18 +1017,20 @@ extern "C" int yume_attn_fwd_ws(const void* Q, int64_t ldq, const void* K, int64
         AttnArgs b = a;
         b.q_lo = (int)lo;
         b.Lq = (int)hi;
-        const int qb = kernel == 4 ? QB4 : QB;
+        const int qb = (kernel == 4 || kernel == 7) ? QB4 : QB;
         b.nqb = (int)((hi - lo + qb - 1) / qb);
         // every XCD slot gets ceil(H/8)*nqb block ids; surplus ids exit immediately
         const dim3 grid((unsigned)(((H + 7) / 8) * b.nqb * 8));
-        if (kernel == 4)
+        if (kernel == 7)
+            yume_attn7_launch(b, st);
+        else if (kernel == 4)
             hipLaunchKernelGGL(attn_fwd_kernel_v4, grid, dim3(NW4 * 64), 0, st, b);
         else if (kernel == 1)
             hipLaunchKernelGGL(attn_fwd_kernel, grid, dim3(NW * 64), 0, st, b);
         else
             hipLaunchKernelGGL(attn_fwd_kernel_v2, grid, dim3(NW * 64), 0, st, b);
     };
-    if (variant == 1 || variant == 2 || variant == 4) {
+    if (variant == 1 || variant == 2 || variant == 4 || variant == 7) {
         run(variant, 0, Lq);
     } else if (Lk < 1536 || Lq < QB4) {
         run(2, 0, Lq);           // few key tiles: the 4-wave kernel's shorter prologue / smaller blocks win (cross-attention)

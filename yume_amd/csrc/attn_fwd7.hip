@@ -1,0 +1,529 @@
+// attn_fwd7.hip — self-attention forward for head_dim 128 on gfx950, ONE wave per SIMD (bf16 in, fp32 accumulate, bf16 out).
+//
+// Same function and the same transposed formulation as attn_fwd.hip (S^T = K Q^T, O^T = V^T P^T, a softmax row lives in one
+// lane and its lane^32 partner), different schedule. The 8-wave kernel there alternates a matrix phase and a softmax phase
+// between the two waves of a SIMD; measured, the partner's VALU work overlaps the MFMAs only by ~45 % (tools/ubench/coissue.hip),
+// while VALU work issued BETWEEN the MFMAs of the same wave is almost free. So here:
+//   * a workgroup is 4 waves (one per SIMD, the whole 512-entry register file each) and 256 queries; a wave owns TWO blocks
+//     of 32 queries, A and B;
+//   * a key tile (64 keys) is processed in two phases of 32 MFMAs:
+//         phase 1(t):  S_A(t+1) = K(t+1) Q_A^T,  O_A += V^T(t) P_A(t)      with softmax_B(t)   issued between the MFMAs
+//         phase 2(t):  S_B(t+1) = K(t+1) Q_B^T,  O_B += V^T(t) P_B(t)      with softmax_A(t+1) issued between the MFMAs
+//     the MFMAs of a phase never depend on the VALU work beside them, so dependent-latency chains of the softmax hide
+//     under the matrix pipe; one piece (<= ~6 instructions) of the softmax sits in each MFMA gap, written out by hand
+//     (sm_piece<I>) and pinned with sched_barriers;
+//   * the exponentials are taken against the block's running base (deferred rescale, P <= 2^8); the row maximum is reduced
+//     beside them and only decides whether the tile is redone against a new base (first tile; then almost never);
+//   * O (a[0:127]) and Q^T (a[128:191]) live in AGPRs this file OWNS: they are named literally in inline asm (MFMAs,
+//     v_accvgpr_read/write) and listed as clobbers of every such statement, so hipcc keeps nothing of its own there
+//     (tests/test_attn7_isa.py audits the generated code for that). hipcc's own choice for a 512-register kernel puts
+//     every accumulator, the scores included, in AGPRs and copies them out for the softmax; with "a"-constrained C++
+//     variables instead it shuffles and spills the 512-bit tuples. The scores S, the packed P and the softmax state stay
+//     compiler-managed VGPRs. Hazards the compiler cannot see (MFMA result -> VALU / accvgpr read) are covered by
+//     distance (>= 16 MFMAs) in the pipelined path and by explicit s_nop pads in the rare paths;
+//   * K / V^T tiles arrive by LDS-DMA into 4 + 4 slots of 16 KiB, three tiles ahead, one counted vmcnt + one workgroup
+//     barrier per tile; fragments go through a 4-deep register ring that runs across phase and tile boundaries.
+// LDS images are those of attn_fwd.hip v2/v4 (K: chunk ^ (row & 15); V^T: chunk ^ ((row >> 1) & 7), swizzled on the DMA source).
+// Roofline: MFMA bf16 dense; algorithmic work 4*Lq*Lk*128 flop per head.
+#include "common.hpp"
+#include "attn_args.hpp"
+#include <type_traits>
+
+namespace {
+
+constexpr int KT = 64;
+constexpr int D = 128;
+constexpr int SLOT = KT * D * 2;          // 16 KiB per tile image
+constexpr int NS = 4;                     // slots per operand
+constexpr int VB = NS * SLOT;             // V^T slots start here
+constexpr int LDS7 = 2 * NS * SLOT;       // 128 KiB
+constexpr int QB7 = 256;                  // queries per workgroup
+constexpr float NEG_BIG = -1.0e30f;
+constexpr float DEFER_LOG2 = 8.0f;
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) const void gbl_cvoid_t;
+
+// ---- the AGPRs this kernel owns -----------------------------------------------------------------------------------------
+//   block A: O^T a[0:63] (d block db at 16*db), Q^T a[128:159] (k-step ks at 4*ks);  block B: O^T a[64:127], Q^T a[160:191]
+constexpr int OA = 0, OB = 64, QA = 128, QB = 160;
+#define AG8(n) "a" #n "0", "a" #n "1", "a" #n "2", "a" #n "3", "a" #n "4", "a" #n "5", "a" #n "6", "a" #n "7", "a" #n "8", "a" #n "9"
+#define OWNED_AGPRS "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", AG8(1), AG8(2), AG8(3), AG8(4), AG8(5), AG8(6), AG8(7), \
+    AG8(8), AG8(9), AG8(10), AG8(11), AG8(12), AG8(13), AG8(14), AG8(15), AG8(16), AG8(17), AG8(18), "a190", "a191"
+// S = K Q^T: D in VGPRs (the softmax reads it), A = K fragment (VGPR, from LDS), B = Q^T fragment a[q:q+3]
+#define MFMA_S0(d, a, q) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, a[%c2:%c3], 0" : "=&v"(d) : "v"(a), "n"(q), "n"((q) + 3) : "memory", OWNED_AGPRS)
+#define MFMA_S(d, a, q) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, a[%c2:%c3], %0" : "+v"(d) : "v"(a), "n"(q), "n"((q) + 3) : "memory", OWNED_AGPRS)
+// O += V^T P^T: C/D = a[o:o+15], A = V^T fragment (VGPR, from LDS), B = P^T fragment (VGPR)
+#define MFMA_O(o, a, b) asm volatile("v_mfma_f32_32x32x16_bf16 a[%c2:%c3], %0, %1, a[%c2:%c3]" ::"v"(a), "v"(b), "n"(o), "n"((o) + 15) : "memory", OWNED_AGPRS)
+template <int R>
+__device__ __forceinline__ void agpr_set(unsigned v) {
+    asm volatile("v_accvgpr_write_b32 a[%c1], %0" ::"v"(v), "n"(R) : OWNED_AGPRS);
+}
+template <int R>
+__device__ __forceinline__ float agpr_get() {
+    float r;
+    asm volatile("v_accvgpr_read_b32 %0, a[%c1]" : "=v"(r) : "n"(R) : OWNED_AGPRS);
+    return r;
+}
+template <int R>
+__device__ __forceinline__ void agpr_scale(float f) {
+    float t;
+    asm volatile("v_accvgpr_read_b32 %0, a[%c2]\n\tv_mul_f32 %0, %0, %1\n\ts_nop 1\n\tv_accvgpr_write_b32 a[%c2], %0" : "=&v"(t) : "v"(f), "n"(R) : OWNED_AGPRS);
+}
+// compile-time loops over register numbers
+template <int R0, int N, typename F>
+__device__ __forceinline__ void for_regs(F&& f) {
+    if constexpr (N > 0) {
+        f(std::integral_constant<int, R0>{});
+        for_regs<R0 + 1, N - 1>(f);
+    }
+}
+#define NOP_PAD() asm volatile("s_nop 15\n\ts_nop 15" ::: "memory")
+// keeps a value (and the instructions that produce it) in the gap it was written in: LLVM otherwise sinks work whose result is only
+// needed after the redo branch into the block behind the phase, out from under the MFMAs
+#define PIN(x) asm volatile("" : "+v"(x))
+
+__device__ __forceinline__ float max3f(float a, float b, float c) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ float max2f(float a, float b) {      // no canonicalising v_max in front (the inputs are never sNaN)
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ float xhalf_max(float v) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return max2f(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float xhalf_sum(float v) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
+// ---- one block of 32 queries ------------------------------------------------------------------------------------------
+struct Soft {
+    float x;            // shifted score of the element whose exponential comes next
+    float p[8];         // exponentials not yet packed
+    float sum0, sum1;   // partial row sums of the current tile
+    float mx;           // max of the raw scores of the current tile
+    float m_new;        // candidate exponent base
+    float m_run;        // exponent base in use (log2 domain)
+    float l_run;        // row sum over this lane's keys
+    int need;           // wave-uniform: the tile has to be redone against m_new
+};
+struct Blk {             // the compiler-managed part of a block (O^T and Q^T are in the owned AGPRs)
+    f32x16 s[2];        // S^T of one key tile
+    u32x4 pf[4];        // P^T fragments of one key tile
+    Soft z;
+};
+
+// Piece I of the pipelined softmax of one key tile (32 scores per lane, element e = 16*b + r):
+//   I = e      : x_e = s_e * c - m                          (I = 0..31)
+//   I = e + 1  : p_e = exp2(x_e)  [masked]                   (I = 1..32)
+//   I = e + 2  : row sum                                     (I = 2..33)
+//   I = 8g + 9, 8g + 10 : pack the 8 exponentials of group g into the P^T fragment g (2 cvt_pk + 1 permlane32_swap each)
+//   I = 0..15  : running max of the raw scores, I = 16 cross-half, I = 17 candidate base + wave vote
+//   I = 34     : l += sums
+// Pieces 0..31 sit in the 32 MFMA gaps of the phase that computes the OTHER block; 32..34 ("drain") sit in the first three
+// gaps of the next phase. Re-running pieces 0..31 rebuilds exactly the state the drain expects (the redo path).
+template <int I, bool MASK>
+__device__ __forceinline__ void sm_piece(Soft& z, const f32x16 (&s)[2], u32x4 (&pf)[4], float c, int keyb, int Lk) {
+    if constexpr (I >= 2 && I <= 33) {
+        constexpr int e = I - 2;
+        if constexpr (e == 0) z.sum0 = z.p[0];
+        else if constexpr (e == 1) z.sum1 = z.p[1];
+        else if constexpr ((e & 1) != 0) { z.sum1 += z.p[e & 7]; PIN(z.sum1); }
+        else { z.sum0 += z.p[e & 7]; PIN(z.sum0); }
+    }
+    if constexpr (I >= 9 && (((I - 9) & 7) < 2)) {
+        constexpr int g = (I - 9) >> 3, i = (I - 9) & 7;
+        const unsigned ev = pack_bf16x2(z.p[2 * i], z.p[2 * i + 1]);
+        const unsigned od = pack_bf16x2(z.p[4 + 2 * i], z.p[4 + 2 * i + 1]);
+        const auto r = __builtin_amdgcn_permlane32_swap(ev, od, false, false);
+        unsigned w0 = r[0], w1 = r[1];
+        PIN(w0);
+        PIN(w1);
+        pf[g][i] = w0;
+        pf[g][2 + i] = w1;
+    }
+    if constexpr (I >= 1 && I <= 32) {
+        constexpr int e = I - 1;
+        float pv = __builtin_amdgcn_exp2f(z.x);
+        if constexpr (MASK) {
+            constexpr int b = e >> 4, r = e & 15;
+            const int key = keyb + 32 * b + (r & 3) + 8 * (r >> 2);
+            pv = key < Lk ? pv : 0.f;
+        }
+        PIN(pv);
+        z.p[e & 7] = pv;
+    }
+    if constexpr (I <= 31) {
+        z.x = __builtin_fmaf(s[I >> 4][I & 15], c, -z.m_run);
+        PIN(z.x);
+    }
+    if constexpr (I == 0) {
+        z.mx = max2f(s[0][0], s[0][1]);
+    } else if constexpr (I <= 15) {
+        constexpr int e = 2 * I;
+        z.mx = max3f(z.mx, s[e >> 4][e & 15], s[e >> 4][(e & 15) + 1]);
+    } else if constexpr (I == 16) {
+        z.mx = xhalf_max(z.mx);
+    } else if constexpr (I == 17) {
+        z.m_new = max2f(z.m_run, z.mx * c);
+        z.need = !__all(z.m_new - z.m_run <= DEFER_LOG2);
+    }
+    if constexpr (I <= 16) PIN(z.mx);
+    if constexpr (I == 34) { z.l_run += z.sum0 + z.sum1; PIN(z.l_run); }
+}
+
+#define REP32(M) M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7) M(8) M(9) M(10) M(11) M(12) M(13) M(14) M(15) \
+                 M(16) M(17) M(18) M(19) M(20) M(21) M(22) M(23) M(24) M(25) M(26) M(27) M(28) M(29) M(30) M(31)
+
+// the tile of block y (O^T at a[YO:YO+63]) has to be redone against y.z.m_new: rescale what was accumulated, rebuild the softmax state
+template <int YO, bool MASK>
+__device__ __forceinline__ void redo_tile(Blk& y, float c, int keyb, int Lk) {
+    NOP_PAD();                                          // pending MFMA results -> accvgpr reads
+    const float alpha = __builtin_amdgcn_exp2f(y.z.m_run - y.z.m_new);
+    y.z.m_run = y.z.m_new;
+    y.z.l_run *= alpha;
+    for_regs<YO, 64>([&](auto r) { agpr_scale<decltype(r)::value>(alpha); });
+#define YUME_P(i) sm_piece<i, MASK>(y.z, y.s, y.pf, c, keyb, Lk);
+    REP32(YUME_P)
+#undef YUME_P
+    NOP_PAD();                                          // accvgpr writes -> MFMA C operands
+}
+
+// ---- LDS-DMA ------------------------------------------------------------------------------------------------------------
+struct Dma7 {
+    const char* kbase;     // K + h*D (bytes), uniform
+    const char* vbase;     // V^T + h*D rows (bytes), uniform
+    int64_t krow;          // bytes per K row
+    unsigned kof[4];       // per-lane source byte offsets of the 4 K pieces of a tile (row rr*16 + tid/16, swizzled chunk)
+    unsigned vof[4];       // ... of the 4 V^T pieces (row rr*32 + tid/8, swizzled chunk)
+    int kr;                // K row of piece 0
+    int kch;               // swizzled K chunk byte offset
+    int vc;                // logical V^T chunk (8 keys)
+};
+
+__device__ __forceinline__ void dma7_init(Dma7& d, const AttnArgs& p, int h, int tid) {
+    d.krow = p.ldk * 2;
+    d.kbase = reinterpret_cast<const char*>(p.K + h * D);
+    d.vbase = reinterpret_cast<const char*>(p.Vt + (int64_t)h * D * p.ldvt);
+    d.kr = tid >> 4;
+    d.kch = ((tid & 15) ^ (d.kr & 15)) << 4;
+    const int dd = tid >> 3;
+    d.vc = (tid & 7) ^ ((dd >> 1) & 7);
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+        d.kof[rr] = (unsigned)((d.kr + 16 * rr) * d.krow) + d.kch;
+        d.vof[rr] = (unsigned)((dd + 32 * rr) * p.ldvt * 2) + (d.vc << 4);    // (dd + 32 rr) >> 1 & 7 == dd >> 1 & 7
+    }
+}
+
+// One LDS-DMA piece: 64 lanes x 16 bytes from sbase + voff[lane] to LDS bytes [lds_dst, lds_dst + 1024). Inline asm so that
+// the address is SGPR base + 32-bit VGPR offset (hipcc builds 64-bit per-lane pointers for the builtin: 16 more VGPRs and a
+// 64-bit add per piece) and so that hipcc does not order later LDS reads behind it with vmcnt(0); completion is counted by
+// the explicit s_waitcnt vmcnt(N) + barrier of the tile loop. M0 is written in the statement that uses it.
+__device__ __forceinline__ void glds16(const char* sbase, unsigned voff, unsigned lds_dst) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+}
+
+// one piece of a full tile: j = 0..3 K rows 16j.., j = 4..7 V^T rows 32(j-4)..   (kslot / vslot: LDS byte addresses)
+template <int J>
+__device__ __forceinline__ void dma7_piece(const Dma7& d, const char* kg, const char* vg, unsigned kslot, unsigned vslot, int wave) {
+    if constexpr (J < 4) glds16(kg, d.kof[J], kslot + J * 4096 + wave * 1024);
+    else glds16(vg, d.vof[J - 4], vslot + (J - 4) * 4096 + wave * 1024);
+}
+
+// whole tiles, any tile (the ragged last one clamps its sources; fix7_v zeroes what must be zero afterwards)
+__device__ __forceinline__ void dma7_k(const Dma7& d, const AttnArgs& p, int t, bool last_ragged, unsigned slot, int wave) {
+    const char* base = d.kbase + (int64_t)t * KT * d.krow;
+    const unsigned l = slot + wave * 1024;
+    if (!last_ragged) {
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) glds16(base, d.kof[rr], l + rr * 4096);
+    } else {
+        const int nrow = p.Lk - t * KT;       // 1..63 valid rows; the others are copies of the last one (their P is masked)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const int r = d.kr + 16 * rr;
+            const int rc = r < nrow ? r : nrow - 1;
+            glds16(base, (unsigned)(rc * d.krow) + d.kch, l + rr * 4096);
+        }
+    }
+}
+__device__ __forceinline__ void dma7_v(const Dma7& d, const AttnArgs& p, int t, bool last_ragged, unsigned slot, int wave) {
+    const char* base = d.vbase + (int64_t)t * KT * 2;
+    const unsigned l = slot + wave * 1024;
+    unsigned back = 0;
+    if (last_ragged) {
+        const int kc = t * KT + d.vc * 8;
+        const int kmax = (int)p.ldvt - 8;
+        if (kc > kmax) back = (unsigned)((kc - kmax) * 2);         // stay inside the row; such a chunk is zeroed afterwards
+    }
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) glds16(base, d.vof[rr] - back, l + rr * 4096);
+}
+// keys >= Lk of the ragged last V^T tile -> 0 (0 * stale bits must be 0), by the thread whose DMA brought the chunk
+__device__ __forceinline__ void fix7_v(const Dma7& d, const AttnArgs& p, int t, char* slot, int tid) {
+    const int nvalid = p.Lk - (t * KT + d.vc * 8);
+    if (nvalid >= 8) return;
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+        u32x4* c = reinterpret_cast<u32x4*>(slot + rr * 4096 + tid * 16);
+        u32x4 x = *c;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            if (2 * w >= nvalid) x[w] = 0u;
+            else if (2 * w + 1 >= nvalid) x[w] &= 0xffffu;
+        }
+        *c = x;
+    }
+}
+
+// ---- a phase: 32 MFMA gaps ------------------------------------------------------------------------------------------------
+struct Ctx {
+    char* smem;
+    unsigned lds0;             // LDS byte address of smem
+    int koff[8], voff[4];      // per-lane fragment offsets inside a K slot / inside V^T slot 0 (VB included)
+    float c;                   // softmax scale * log2(e)
+    int keyh;                  // 4 * (lane >> 5)
+    int Lk;
+    int wave;
+};
+
+// fragment F of a phase: F < 16 -> K fragment (k-step F>>1, key half F&1) of the slot at kb; else V^T fragment
+// (key group (F-16)>>2, d block (F-16)&3) of the slot at vb
+template <int F>
+__device__ __forceinline__ u32x4 frag(const Ctx& cx, int kb, int vb) {
+    if constexpr (F < 16)
+        return *reinterpret_cast<const u32x4*>(cx.smem + kb + cx.koff[F >> 1] + (F & 1) * (32 * 256));
+    else
+        return *reinterpret_cast<const u32x4*>(cx.smem + vb + cx.voff[(F - 16) >> 2] + ((F - 16) & 3) * (32 * 128));
+}
+
+// X (O^T at a[XO..], Q^T at a[XQ..]): the block whose MFMAs run (S of the tile in K slot kb if DO_S, O += V^T P of the tile in V slot vb if DO_PV) and whose
+//    previous softmax drains in the first gaps (DRAIN, tile starting at key jx);
+// Y (O^T at a[YO..]): the block whose softmax pieces fill the gaps (SM, tile starting at key jy).
+// CIN: ring[0..3] already hold this phase's first four fragments; COUT: the last four gaps fetch K fragments 0..3 of slot nkb.
+// DMA: gaps 0..7 issue one LDS-DMA piece each (K tile at kg -> kslot, V^T tile at vg -> vslot).
+template <int XO, int XQ, int YO, bool DO_S, bool DO_PV, bool DRAIN, bool MASKX, bool SM, bool MASKY, bool DMA, bool CIN, bool COUT>
+__device__ __forceinline__ void phase(const Ctx& cx, Blk& X, Blk& Y, u32x4 (&ring)[4], int kb, int vb, int nkb, int jx, int jy,
+                                      const Dma7& dp, const char* kg, const char* vg, unsigned kslot, unsigned vslot) {
+    constexpr int F0 = DO_S ? 0 : 16;
+    if constexpr (!CIN && (DO_S || DO_PV)) {
+        ring[0] = frag<F0 + 0>(cx, kb, vb);
+        ring[1] = frag<F0 + 1>(cx, kb, vb);
+        ring[2] = frag<F0 + 2>(cx, kb, vb);
+        ring[3] = frag<F0 + 3>(cx, kb, vb);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#define YUME_GAP(i)                                                                                          \
+    {                                                                                                        \
+        if constexpr ((i) < 16) {                                                                            \
+            if constexpr (DO_S) {                                                                            \
+                if constexpr (((i) >> 1) == 0) MFMA_S0(X.s[(i) & 1], ring[(i) & 3], XQ);                 \
+                else MFMA_S(X.s[(i) & 1], ring[(i) & 3], XQ + 4 * ((i) >> 1));                                     \
+            }                                                                                                \
+        } else if constexpr (DO_PV) {                                                                        \
+            MFMA_O(XO + 16 * (((i) - 16) & 3), ring[(i) & 3], X.pf[((i) - 16) >> 2]);                               \
+        }                                                                                                    \
+        if constexpr ((i) + 4 < 32) {                                                                        \
+            if constexpr ((i) + 4 >= 16 ? DO_PV : DO_S) ring[(i) & 3] = frag<((i) + 4) & 31>(cx, kb, vb);    \
+        } else if constexpr (COUT) {                                                                         \
+            ring[(i) & 3] = frag<((i) + 4) & 15>(cx, nkb, 0);                                                \
+        }                                                                                                    \
+        if constexpr (DMA && (i) < 8) dma7_piece<(i) & 7>(dp, kg, vg, kslot, vslot, cx.wave);                \
+        if constexpr (DRAIN && (i) < 3) sm_piece<32 + ((i) & 3), MASKX>(X.z, X.s, X.pf, cx.c, jx + cx.keyh, cx.Lk); \
+        if constexpr (SM) sm_piece<(i), MASKY>(Y.z, Y.s, Y.pf, cx.c, jy + cx.keyh, cx.Lk);                   \
+        __builtin_amdgcn_sched_barrier(0);                                                                   \
+    }
+    REP32(YUME_GAP)
+#undef YUME_GAP
+    if constexpr (SM) {
+        if (__builtin_expect(Y.z.need, 0)) redo_tile<YO, MASKY>(Y, cx.c, jy + cx.keyh, cx.Lk);
+    }
+}
+
+template <int XO>
+__device__ __forceinline__ void store_block(const AttnArgs& p, const Blk& x, int q, int h, int hi) {
+    const float l_tot = xhalf_sum(x.z.l_run);
+    const float inv = 1.0f / l_tot;
+    float o[64];
+    for_regs<0, 64>([&](auto r) { o[decltype(r)::value] = agpr_get<XO + decltype(r)::value>() * inv; });
+    if (q < p.Lq) {
+        unsigned short* op = p.O + (int64_t)q * p.ldo + h * D + 4 * hi;
+#pragma unroll
+        for (int db = 0; db < 4; ++db)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float v0 = o[16 * db + 4 * g + 0], v1 = o[16 * db + 4 * g + 1];
+                float v2 = o[16 * db + 4 * g + 2], v3 = o[16 * db + 4 * g + 3];
+                u32x2* dst = reinterpret_cast<u32x2*>(op + 32 * db + 8 * g);
+                if (p.accumulate) {
+                    const u32x2 old = *dst;
+                    v0 += bf16_to_f32((unsigned short)(old[0] & 0xffffu));
+                    v1 += bf16_to_f32((unsigned short)(old[0] >> 16));
+                    v2 += bf16_to_f32((unsigned short)(old[1] & 0xffffu));
+                    v3 += bf16_to_f32((unsigned short)(old[1] >> 16));
+                }
+                u32x2 w;
+                w[0] = pack_bf16x2(v0, v1);
+                w[1] = pack_bf16x2(v2, v3);
+                *dst = w;
+            }
+    }
+}
+
+// Q^T fragments of the block's query (lane (q, hi) holds Q[q][16*ks + 8*hi .. +7]) -> a[XQ + 4*ks ..]; O^T = 0; softmax state
+template <int XO, int XQ>
+__device__ __forceinline__ void load_q(const AttnArgs& p, Blk& x, int q, int h, int hi) {
+    q = q < p.Lq ? q : p.Lq - 1;
+    const unsigned short* qp = p.Q + (int64_t)q * p.ldq + h * D + 8 * hi;
+    u32x4 qf[8];
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) qf[ks] = *reinterpret_cast<const u32x4*>(qp + 16 * ks);
+    for_regs<0, 32>([&](auto r) { agpr_set<XQ + decltype(r)::value>(qf[decltype(r)::value >> 2][decltype(r)::value & 3]); });
+    for_regs<XO, 64>([&](auto r) { agpr_set<decltype(r)::value>(0u); });
+    x.z.m_run = NEG_BIG;
+    x.z.l_run = 0.f;
+    x.z.need = 0;
+    x.z.sum0 = x.z.sum1 = 0.f;
+    x.z.x = 0.f;
+    x.z.mx = 0.f;
+    x.z.m_new = NEG_BIG;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) x.z.p[i] = 0.f;
+}
+
+// steady-state tile t (TS = t % 4): 1 <= t, t + 4 < number of FULL tiles; every LDS address is a compile-time constant
+template <int TS>
+__device__ __forceinline__ void steady7(const Ctx& cx, const Dma7& dp, int t, Blk& A, Blk& B, u32x4 (&ring)[4]) {
+    constexpr int kb = ((TS + 1) & 3) * SLOT, vb = TS * SLOT, nkb = ((TS + 2) & 3) * SLOT;
+    const char* kg = dp.kbase + (int64_t)(t + 4) * KT * dp.krow;
+    const char* vg = dp.vbase + (int64_t)(t + 3) * KT * 2;
+    const unsigned kslot = cx.lds0 + TS * SLOT;
+    const unsigned vslot = cx.lds0 + VB + ((TS + 3) & 3) * SLOT;
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");      // everything older than the previous tile's 8 pieces has landed
+    __builtin_amdgcn_s_barrier();
+    phase<OA, QA, OB, true, true, true, false, true, false, true, true, true>(cx, A, B, ring, kb, vb, kb, 0, 0, dp, kg, vg, kslot, vslot);
+    phase<OB, QB, OA, true, true, true, false, true, false, false, true, true>(cx, B, A, ring, kb, vb, nkb, 0, 0, dp, kg, vg, kslot, vslot);
+}
+
+// any tile t (runtime slots; the softmax pieces always carry the key mask)
+__device__ __forceinline__ void general7(const Ctx& cx, const Dma7& dp, const AttnArgs& p, int t, int nt, bool ragged, int tid,
+                                         Blk& A, Blk& B, u32x4 (&ring)[4]) {
+    const int last = nt - 1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (ragged && t == (last >= 2 ? last - 2 : 0) && last >= 3) fix7_v(dp, p, last, cx.smem + VB + (last & 3) * SLOT, tid);
+    __builtin_amdgcn_s_barrier();
+    if (t + 4 < nt) dma7_k(dp, p, t + 4, ragged && t + 4 == last, cx.lds0 + ((t + 4) & 3) * SLOT, cx.wave);
+    if (t + 3 < nt) dma7_v(dp, p, t + 3, ragged && t + 3 == last, cx.lds0 + VB + ((t + 3) & 3) * SLOT, cx.wave);
+    const int kb = ((t + 1) & 3) * SLOT, vb = (t & 3) * SLOT;
+    const int j = t * KT;
+    if (t + 1 < nt) {
+        phase<OA, QA, OB, true, true, true, true, true, true, false, false, false>(cx, A, B, ring, kb, vb, 0, j, j, dp, nullptr, nullptr, 0u, 0u);
+        phase<OB, QB, OA, true, true, true, true, true, true, false, false, false>(cx, B, A, ring, kb, vb, 0, j, j + KT, dp, nullptr, nullptr, 0u, 0u);
+    } else {
+        phase<OA, QA, OB, false, true, true, true, true, true, false, false, false>(cx, A, B, ring, kb, vb, 0, j, j, dp, nullptr, nullptr, 0u, 0u);
+        phase<OB, QB, OA, false, true, true, true, false, true, false, false, false>(cx, B, A, ring, kb, vb, 0, j, j, dp, nullptr, nullptr, 0u, 0u);
+    }
+}
+
+__global__ __launch_bounds__(256, 1) void attn_fwd_kernel_v7(AttnArgs p) {
+    __shared__ __attribute__((aligned(16))) char smem[LDS7];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int hi = lane >> 5;
+    const int ql = lane & 31;
+    int h, qb;
+    {
+        const int bid = blockIdx.x;
+        const int xcd = bid & 7, idx = bid >> 3;
+        const int hx = (p.H + 7 - xcd) >> 3;
+        const int per = hx * p.nqb;
+        if (idx >= per) return;
+        h = xcd + 8 * (idx / p.nqb);
+        qb = idx % p.nqb;
+    }
+    const int q0 = p.q_lo + qb * QB7 + wave * 64;
+
+    Ctx cx;
+    cx.smem = smem;
+    cx.lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    cx.c = p.scale_log2;
+    cx.keyh = 4 * hi;
+    cx.Lk = p.Lk;
+    cx.wave = wave;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) cx.koff[ks] = ql * 256 + (((2 * ks + hi) ^ (ql & 15)) << 4);
+#pragma unroll
+    for (int sg = 0; sg < 4; ++sg) cx.voff[sg] = VB + ql * 128 + (((2 * sg + hi) ^ ((ql >> 1) & 7)) << 4);
+
+    Dma7 dp;
+    dma7_init(dp, p, h, tid);
+    const int nt = (p.Lk + KT - 1) / KT;
+    const bool ragged = (p.Lk % KT) != 0;
+    const int nfull = ragged ? nt - 1 : nt;
+    const int last = nt - 1;
+
+    Blk A, B;
+    load_q<OA, QA>(p, A, q0 + ql, h, hi);
+    load_q<OB, QB>(p, B, q0 + 32 + ql, h, hi);
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- prologue DMA: K(0) | K(1) V(0) | K(2) V(1) | K(3) V(2) ----
+    dma7_k(dp, p, 0, ragged && last == 0, cx.lds0, wave);
+    if (nt > 1) dma7_k(dp, p, 1, ragged && last == 1, cx.lds0 + SLOT, wave);
+    dma7_v(dp, p, 0, ragged && last == 0, cx.lds0 + VB, wave);
+    if (nt > 2) dma7_k(dp, p, 2, ragged && last == 2, cx.lds0 + 2 * SLOT, wave);
+    if (nt > 1) dma7_v(dp, p, 1, ragged && last == 1, cx.lds0 + VB + SLOT, wave);
+    if (nt > 3) dma7_k(dp, p, 3, ragged && last == 3, cx.lds0 + 3 * SLOT, wave);
+    if (nt > 2) dma7_v(dp, p, 2, ragged && last == 2, cx.lds0 + VB + 2 * SLOT, wave);
+
+    __builtin_amdgcn_sched_barrier(0);
+    if (nt > 3) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");      // K(0) has landed (Q loads are older still)
+    else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (ragged && last <= 2) fix7_v(dp, p, last, smem + VB + last * SLOT, tid);
+    }
+    __builtin_amdgcn_s_barrier();
+    NOP_PAD();
+
+    u32x4 ring[4];
+    // S_A(0), then S_B(0) beside softmax_A(0)
+    phase<OA, QA, OB, true, false, false, true, false, true, false, false, false>(cx, A, B, ring, 0, 0, 0, 0, 0, dp, nullptr, nullptr, 0u, 0u);
+    phase<OB, QB, OA, true, false, false, true, true, true, false, false, false>(cx, B, A, ring, 0, 0, 0, 0, 0, dp, nullptr, nullptr, 0u, 0u);
+
+    general7(cx, dp, p, 0, nt, ragged, tid, A, B, ring);
+    int t = 1;
+    if (t + 7 < nfull) {
+        // first four fragments of phase 1(1): K(2), published by the barrier of tile 0
+        ring[0] = frag<0>(cx, 2 * SLOT, 0);
+        ring[1] = frag<1>(cx, 2 * SLOT, 0);
+        ring[2] = frag<2>(cx, 2 * SLOT, 0);
+        ring[3] = frag<3>(cx, 2 * SLOT, 0);
+#pragma unroll 1
+        for (; t + 7 < nfull; t += 4) {        // t % 4 == 1; the four calls issue tiles up to t + 7 (all full)
+            steady7<1>(cx, dp, t, A, B, ring);
+            steady7<2>(cx, dp, t + 1, A, B, ring);
+            steady7<3>(cx, dp, t + 2, A, B, ring);
+            steady7<0>(cx, dp, t + 3, A, B, ring);
+        }
+    }
+#pragma unroll 1
+    for (; t < nt; ++t) general7(cx, dp, p, t, nt, ragged, tid, A, B, ring);
+
+    NOP_PAD();
+    store_block<OA>(p, A, q0 + ql, h, hi);
+    store_block<OB>(p, B, q0 + 32 + ql, h, hi);
+}
+
+}  // namespace
+
+void yume_attn7_launch(const AttnArgs& a, hipStream_t st) {
+    const dim3 grid((unsigned)(((a.H + 7) / 8) * a.nqb * 8));
+    hipLaunchKernelGGL(attn_fwd_kernel_v7, grid, dim3(256), 0, st, a);
+}
