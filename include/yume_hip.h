@@ -35,7 +35,8 @@ extern "C" {
 
 /* ---- library info ------------------------------------------------------------------- */
 const char* yume_last_error(void);
-/* ABI version of this header; bumped on any signature change. */
+/* ABI version of this header; bumped on any signature change (yume_amd/_lib.py refuses a library that reports another one). */
+#define YUME_ABI_VERSION 3
 int yume_abi_version(void);
 /* name of the gfx target the kernels were compiled for ("gfx950"). */
 const char* yume_target_arch(void);
@@ -128,16 +129,16 @@ int yume_rmsnorm_rows_periodic(void* buf, int64_t ld, int64_t T, int64_t C, cons
  *     ldvt % 8 == 0 (the image written by YUME_EPI_BF16_SPLITT / yume_transpose_bf16).
  * O: bf16 token-major (ldo). accumulate != 0: O += result (the 14B image cross-attention sum,
  *    wan/modules/model.py:379-387) using the fp32 accumulator before rounding.
- * variant: 0 = automatic (Lk >= 1536: 8-wave ping-pong kernel on whole rounds of 256-query workgroups + the 4-wave
- *    kernel on the remaining query rows; otherwise the 4-wave kernel), 1 = 4-wave register-staged kernel,
- *    2 = 4-wave LDS-DMA kernel, 4 = 8-wave ping-pong kernel. All compute the same function (tests compare them).
+ * variant: 0 = automatic (Lk >= 1536 and Lq >= 256: the one-wave-per-SIMD kernel, 256 queries per workgroup; otherwise
+ *    the 4-wave LDS-DMA kernel), 1 = 4-wave register-staged kernel, 2 = 4-wave LDS-DMA kernel, 4 = 8-wave ping-pong
+ *    kernel, 7 = one-wave-per-SIMD kernel (attn_fwd7.hip). All compute the same function (tests compare them).
  */
 int yume_attn_fwd(const void* Q, int64_t ldq, const void* K, int64_t ldk, const void* Vt, int64_t ldvt,
                   void* O, int64_t ldo, int64_t Lq, int64_t Lk, int64_t H, float scale,
                   int accumulate, int variant, void* stream);
 /* Same call with caller-owned scratch (yume_attn_workspace_bytes(Lq, Lk, H) bytes, 0 = none needed; 16-byte aligned): in the
- * automatic mode the query rows left to the 4-wave kernel are then computed as TWO key-range halves per workgroup (fp32 partial
- * O, running max and row sum in the scratch) merged in a fixed order, so that two workgroups share a CU there as well. */
+ * automatic mode the query blocks that would form a partial last round of workgroups are then cut into 2-4 key ranges inside
+ * the same launch (fp32 partial O, running max and row sum in the scratch) and merged in a fixed order. */
 int64_t yume_attn_workspace_bytes(int64_t Lq, int64_t Lk, int64_t H);
 int yume_attn_fwd_ws(const void* Q, int64_t ldq, const void* K, int64_t ldk, const void* Vt, int64_t ldvt,
                      void* O, int64_t ldo, int64_t Lq, int64_t Lk, int64_t H, float scale,

@@ -29,7 +29,8 @@ def test_build_and_exports():
 def test_info_calls_without_gpu():
     from yume_amd import _lib
     lib = _lib.load()
-    assert lib.yume_abi_version() == 1
+    hdr = open(os.path.join(ROOT, "include", "yume_hip.h")).read()
+    assert lib.yume_abi_version() == _lib.ABI_VERSION == int(re.search(r"#define YUME_ABI_VERSION (\d+)", hdr).group(1))
     assert lib.yume_target_arch() == b"gfx950"
 
 
@@ -52,3 +53,13 @@ def test_product_path_has_no_oracle_import():
             if f.endswith(".py"):
                 txt = open(os.path.join(dp, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M), os.path.join(dp, f)
+
+
+def test_stale_library_is_refused(monkeypatch):
+    """a library reporting another ABI version must not be bound (ctypes signatures would not match its argument lists)."""
+    import pytest
+    from yume_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "ABI_VERSION", _lib.ABI_VERSION + 1)
+    with pytest.raises(RuntimeError, match="ABI version"):
+        _lib.load()

@@ -177,7 +177,7 @@ def run_attn(q, k, v, scale=None, accumulate=None, variant=0):
 
 @pytest.mark.parametrize("Lq,Lk,H", [(1, 1, 2), (1, 300, 2), (300, 1, 2), (5, 63, 1), (128, 64, 1), (32, 128, 2), (300, 300, 3), (1000, 512, 4), (517, 257, 2), (2048, 2048, 8),
                                      (64, 1, 1), (1, 77, 3), (130, 1000, 24), (200, 640, 2), (100, 65, 1)])
-@pytest.mark.parametrize("variant", [0, 1, 2, 4])
+@pytest.mark.parametrize("variant", [0, 1, 2, 4, 7])
 def test_attention_matches_exact_softmax(Lq, Lk, H, variant):
     q, k, v = (rnd(L, H, 128, seed=s, dtype=torch.bfloat16) for L, s in ((Lq, 1), (Lk, 2), (Lk, 3)))
     want = attn_ref(q, k, v, 1 / math.sqrt(128))
@@ -188,7 +188,7 @@ def test_attention_matches_exact_softmax(Lq, Lk, H, variant):
     assert rel_l2(got, want) < 6e-3
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 4])
+@pytest.mark.parametrize("variant", [0, 1, 2, 4, 7])
 def test_attention_rescale_branch_and_scale(variant):
     """a key that spikes late forces the running max to jump (online-softmax rescale) in a chosen tile."""
     Lq, Lk, H = 96, 640, 2
@@ -201,7 +201,7 @@ def test_attention_rescale_branch_and_scale(variant):
         assert (got.double() - want).abs().max() <= 2e-2 * want.abs().max()
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 4])
+@pytest.mark.parametrize("variant", [0, 1, 2, 4, 7])
 def test_attention_accumulate_and_transposed_operand(variant):
     Lq, Lk, H = 200, 257, 2
     q, k, v = (rnd(L, H, 128, seed=s, dtype=torch.bfloat16) for L, s in ((Lq, 7), (Lk, 8), (Lk, 9)))
@@ -220,9 +220,10 @@ def test_attention_accumulate_and_transposed_operand(variant):
 
 
 def test_attention_auto_splits_query_range_between_kernels():
-    """variant 0 at Lk >= 1536: whole rounds of 256-query workgroups on the 8-wave kernel, the remaining query rows on
-    the 4-wave kernel (here 8 heads x 34 blocks = 1 round of 32 + 2 -> rows [0, 8192) / [8192, 8500))."""
-    Lq, Lk, H = 8500, 1600, 8
+    """variant 0 at Lk >= 1536: 256-query workgroups of the one-wave-per-SIMD kernel; the query blocks of a partial last round
+    are cut into key ranges inside the same launch (here 1 head per XCD x 34 blocks = 1 round of 32 + 2 -> rows [0, 8192) whole,
+    [8192, 8500) as two key halves each)."""
+    Lq, Lk, H = 8500, 2100, 8
     q, k, v = rnd(Lq, H * 128, seed=1, dtype=torch.bfloat16), rnd(Lk, H * 128, seed=2, dtype=torch.bfloat16), rnd(Lk, H * 128, seed=3, dtype=torch.bfloat16)
     base = rnd(Lq, H * 128, seed=4, dtype=torch.bfloat16).to(DEV)
     for acc in (False, True):

@@ -10,7 +10,17 @@
 #include <stdlib.h>
 #include <string.h>
 #include <vector>
+#include <dlfcn.h>
 #include "../include/yume_hip.h"
+
+// the library under test is dlopen()ed so that timing-experiment builds (other .so files) can be compared by the same binary
+typedef int (*attn_fn)(const void*, int64_t, const void*, int64_t, const void*, int64_t, void*, int64_t, int64_t, int64_t, int64_t, float, int, int, void*, int64_t, void*);
+typedef int64_t (*ws_fn)(int64_t, int64_t, int64_t);
+typedef const char* (*err_fn)();
+static attn_fn p_attn; static ws_fn p_ws; static err_fn p_err;
+#define yume_attn_fwd_ws p_attn
+#define yume_attn_workspace_bytes p_ws
+#define yume_last_error p_err
 
 #define HC(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(2); } } while (0)
 
@@ -126,12 +136,26 @@ static double maxdiff2(const std::vector<uint16_t>& a, const std::vector<uint16_
 
 int main(int argc, char** argv) {
     std::vector<int> variants;
-    for (int i = 1; i < argc; ++i) variants.push_back(atoi(argv[i]));
+    const char* lib = "yume_amd/lib/libyume_hip.so";
+    bool timing_only = false;
+    int one[3] = {0, 0, 0};
+    for (int i = 1; i < argc; ++i) {
+        if (!strcmp(argv[i], "--lib")) lib = argv[++i];
+        else if (!strcmp(argv[i], "--timing")) timing_only = true;
+        else if (!strcmp(argv[i], "--one")) { one[0] = atoi(argv[i + 1]); one[1] = atoi(argv[i + 2]); one[2] = atoi(argv[i + 3]); i += 3; timing_only = true; }
+        else variants.push_back(atoi(argv[i]));
+    }
+    void* hnd = dlopen(lib, RTLD_NOW);
+    if (!hnd) { printf("dlopen %s: %s\n", lib, dlerror()); return 2; }
+    p_attn = (attn_fn)dlsym(hnd, "yume_attn_fwd_ws"); p_ws = (ws_fn)dlsym(hnd, "yume_attn_workspace_bytes"); p_err = (err_fn)dlsym(hnd, "yume_last_error");
+    printf("library %s\n", lib);
     if (variants.empty()) variants = {7, 4, 2, 0};
     int fails = 0;
     const int small[][4] = {{256, 64, 1, 0}, {64, 40, 1, 0}, {1, 1, 1, 0}, {300, 200, 2, 0}, {273, 323, 3, 0}, {256, 256, 1, 0}, {256, 320, 1, 0},
-                            {513, 640, 9, 0}, {700, 1000, 8, 1}, {256, 577, 2, 1}, {260, 448, 1, 0}, {512, 512, 3, 1}, {384, 1999, 2, 1}};
+                            {513, 640, 9, 0}, {700, 1000, 8, 1}, {256, 577, 2, 1}, {260, 448, 1, 0}, {512, 512, 3, 1}, {384, 1999, 2, 1},
+                            {700, 2100, 8, 1}, {1000, 3333, 16, 1}, {300, 1536, 1, 0}};
     for (auto& sh : small) {
+        if (timing_only) break;
         for (int acc = 0; acc < 2; ++acc) {
             Prob p; make(p, sh[0], sh[1], sh[2], sh[3]);
             std::vector<float> ref; reference(p, acc, ref);
@@ -147,8 +171,19 @@ int main(int argc, char** argv) {
             drop(p);
         }
     }
-    const int big[][3] = {{9460, 9460, 24}, {8192, 9460, 24}, {2048, 4096, 16}, {23460, 23460, 40}};
+    const int big[][3] = {{9460, 9460, 24}, {8192, 9460, 24}, {9460, 512, 24}, {2048, 4096, 16}, {23460, 23460, 40}, {27810, 27810, 40}};
+    if (one[0]) {      // a single problem, the listed variants only (profiling runs)
+        Prob p; make(p, one[0], one[1], one[2], 0);
+        for (int v : variants) {
+            std::vector<uint16_t> out;
+            for (int i = 0; i < 3; ++i) run(p, v, 0, out);
+        }
+        drop(p);
+        return 0;
+    }
+    int nbig = 0;
     for (auto& sh : big) {
+        if (timing_only && nbig++ >= 3) break;
         Prob p; make(p, sh[0], sh[1], sh[2], 1);
         std::vector<uint16_t> base;
         if (run(p, 2, 0, base)) { ++fails; drop(p); continue; }
@@ -164,7 +199,7 @@ int main(int argc, char** argv) {
             HC(hipEventRecord(e1, nullptr)); HC(hipEventSynchronize(e1));
             float ms; HC(hipEventElapsedTime(&ms, e0, e1)); ms /= it;
             const double tf = 4.0 * sh[0] * sh[1] * 128.0 * sh[2] / (ms * 1e-3) / 1e12;
-            const bool ok = nan == 0 && md < 3e-2;
+            const bool ok = timing_only || (nan == 0 && md < 3e-2);
             printf("big Lq=%d Lk=%d H=%d variant=%d  vs v2 maxabs=%.3e nan=%d %s   %.3f ms  %.0f TFLOP/s\n", sh[0], sh[1], sh[2], v, md, nan, ok ? "ok" : "FAIL", ms, tf);
             if (!ok) ++fails;
         }

@@ -49,6 +49,7 @@ SIGNATURES = {
 _RES = {"yume_last_error": c_char_p, "yume_target_arch": c_char_p, "yume_gemm_splitk_workspace_bytes": c_int64, "yume_attn_workspace_bytes": c_int64}
 
 _lib = None
+ABI_VERSION = 3          # must equal YUME_ABI_VERSION in include/yume_hip.h; bumped whenever an argument list changes
 
 
 def load():
@@ -66,6 +67,12 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.argtypes = argtypes
         fn.restype = _RES.get(name, c_int)
+    # the .so is built out of band (git-ignored): a stale one with the same symbol names but other argument lists would be
+    # called with the wrong ctypes signatures, so refuse anything but this binding's ABI and target
+    got, arch = int(lib.yume_abi_version()), lib.yume_target_arch()
+    if got != ABI_VERSION or arch != b"gfx950":
+        raise RuntimeError(f"{LIB_PATH} has ABI version {got} for {arch!r}, this binding needs {ABI_VERSION} for gfx950: "
+                           "rebuild with `python -m yume_amd.build --force`")
     _lib = lib
     return lib
 

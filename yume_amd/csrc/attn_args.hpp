@@ -17,6 +17,9 @@ struct AttnArgs {
     // its UNNORMALISED O (fp32) + running max + row sum here; attn_combine_kernel merges the splits
     float* part_o;     // [splits, Lq - q_lo, H*128]
     float* part_ml;    // [splits, Lq - q_lo, H, 2]
+    // v7 kernel only: query blocks >= tail_qb are cut into `splits` key ranges inside the same launch (their pieces are dispatched
+    // after the whole blocks and fill the partial last round of workgroups); partials as above with rows = Lq - (q_lo + 256*tail_qb)
+    int tail_qb, splits;
 };
 
 // attn_fwd7.hip: 4-wave / 64-queries-per-wave kernel (one wave per SIMD, 512 registers); grid = ceil(H/8) * nqb * 8 blocks

@@ -964,20 +964,47 @@ __global__ __launch_bounds__(256) void attn_combine_kernel(const float* __restri
 }  // namespace
 
 
-// query rows the automatic selection leaves to the 4-wave kernel after whole rounds of 8-wave workgroups (0: none / not applicable)
-static int64_t attn_tail_start(int64_t Lq, int64_t Lk, int64_t H) {
-    if (Lk < 1536 || Lq < QB4) return -1;
-    const int64_t hx = (H + 7) / 8, nq4 = (Lq + QB4 - 1) / QB4;
-    const int64_t nb = hx * nq4, R = nb / 32, r = nb % 32;
-    const int64_t nq_main = R >= 1 ? (32 * R) / hx : 0;
-    if (r > 0 && r <= 20 && nq_main >= 1 && nq_main < nq4) return nq_main * QB4;
-    return -1;
+// ---- launch plan of the one-wave-per-SIMD kernel (attn_fwd7.hip) ------------------------------------------------------------
+// An XCD owns ceil(H/8) heads x nq query blocks of 256 rows = that many workgroups of equal length on its 32 CUs; a partial
+// last round costs a whole round. The last `tail_q` query blocks of every head can instead be cut into `splits` key ranges
+// whose pieces are dispatched behind the whole blocks (same launch) and merged by attn_combine_kernel. The plan minimises the
+// makespan of that in-order dispatch under a simple cost model (a piece = 1/splits of a block + a fixed prologue share).
+struct Plan7 { int64_t tail_qb; int splits; };
+static Plan7 attn7_plan(int64_t Lq, int64_t Lk, int64_t H) {
+    const int64_t nq = (Lq + QB4 - 1) / QB4, hx = (H + 7) / 8, nt = (Lk + KT - 1) / KT;
+    Plan7 best{nq, 1};
+    auto makespan = [&](int64_t tail_q, int splits) {
+        double cu[32];
+        for (double& c : cu) c = 0.0;
+        auto put = [&](double cost) {
+            int m = 0;
+            for (int i = 1; i < 32; ++i) if (cu[i] < cu[m]) m = i;
+            cu[m] += cost;
+        };
+        for (int64_t i = 0; i < hx * (nq - tail_q); ++i) put(1.0);
+        for (int64_t i = 0; i < hx * tail_q * splits; ++i) put(1.0 / splits + 0.04);
+        double mx = 0.0;
+        for (double c : cu) mx = c > mx ? c : mx;
+        return mx + (splits > 1 ? 0.03 : 0.0);       // + the merge pass
+    };
+    double bm = makespan(0, 1);
+    for (int splits = 2; splits <= 4; ++splits) {
+        if (nt / splits < 16) break;
+        for (int64_t tail_q = 1; tail_q <= nq && tail_q <= 12; ++tail_q) {
+            const double m = makespan(tail_q, splits);
+            if (m < bm - 0.02) { bm = m; best = Plan7{nq - tail_q, splits}; }
+        }
+    }
+    return best;
 }
+static bool attn7_applies(int64_t Lq, int64_t Lk) { return Lk >= 1536 && Lq >= QB4; }
 
 extern "C" int64_t yume_attn_workspace_bytes(int64_t Lq, int64_t Lk, int64_t H) {
-    const int64_t start = attn_tail_start(Lq, Lk, H);
-    if (start < 0) return 0;
-    return 2 * (Lq - start) * (H * D + H * 2) * 4;
+    if (Lq <= 0 || Lk <= 0 || H <= 0 || !attn7_applies(Lq, Lk)) return 0;
+    const Plan7 pl = attn7_plan(Lq, Lk, H);
+    if (pl.splits == 1) return 0;
+    const int64_t rows = Lq - pl.tail_qb * QB4;
+    return (int64_t)pl.splits * rows * (H * D + H * 2) * 4;
 }
 
 extern "C" int yume_attn_fwd_ws(const void* Q, int64_t ldq, const void* K, int64_t ldk, const void* Vt, int64_t ldvt,
@@ -997,6 +1024,7 @@ extern "C" int yume_attn_fwd_ws(const void* Q, int64_t ldq, const void* K, int64
     YUME_REQUIRE(Lq > 0 && Lk > 0 && H > 0, "attn_fwd: empty problem Lq=%lld Lk=%lld H=%lld", (long long)Lq, (long long)Lk, (long long)H);
     YUME_REQUIRE(Lq < (1ll << 30) && Lk < (1ll << 30) && H < 65536, "attn_fwd: dimension too large");
     YUME_REQUIRE((ldq % 8) == 0 && (ldk % 8) == 0 && (ldvt % 8) == 0 && (ldo % 4) == 0, "attn_fwd: ldq/ldk/ldvt must be multiples of 8, ldo of 4");
+    YUME_REQUIRE(ldk < (1ll << 24) && ldvt < (1ll << 24), "attn_fwd: ldk / ldvt too large for 32-bit tile offsets");
     YUME_REQUIRE(ldvt >= Lk && ldvt >= 8, "attn_fwd: ldvt=%lld must be >= Lk=%lld", (long long)ldvt, (long long)Lk);
     YUME_REQUIRE(((uintptr_t)Q % 16) == 0 && ((uintptr_t)K % 16) == 0 && ((uintptr_t)Vt % 16) == 0 && ((uintptr_t)O % 8) == 0, "attn_fwd: pointer alignment");
     AttnArgs a;
@@ -1011,6 +1039,8 @@ extern "C" int yume_attn_fwd_ws(const void* Q, int64_t ldq, const void* K, int64
     a.nqb = 0;
     a.part_o = nullptr;
     a.part_ml = nullptr;
+    a.tail_qb = 0;
+    a.splits = 1;
     hipStream_t st = (hipStream_t)stream;
     // launch one kernel over the query rows [lo, hi)
     auto run = [&](int kernel, int64_t lo, int64_t hi) {
@@ -1019,6 +1049,8 @@ extern "C" int yume_attn_fwd_ws(const void* Q, int64_t ldq, const void* K, int64
         b.Lq = (int)hi;
         const int qb = (kernel == 4 || kernel == 7) ? QB4 : QB;
         b.nqb = (int)((hi - lo + qb - 1) / qb);
+        b.tail_qb = b.nqb;
+        b.splits = 1;
         // every XCD slot gets ceil(H/8)*nqb block ids; surplus ids exit immediately
         const dim3 grid((unsigned)(((H + 7) / 8) * b.nqb * 8));
         if (kernel == 7)
@@ -1032,37 +1064,27 @@ extern "C" int yume_attn_fwd_ws(const void* Q, int64_t ldq, const void* K, int64
     };
     if (variant == 1 || variant == 2 || variant == 4 || variant == 7) {
         run(variant, 0, Lq);
-    } else if (Lk < 1536 || Lq < QB4) {
-        run(2, 0, Lq);           // few key tiles: the 4-wave kernel's shorter prologue / smaller blocks win (cross-attention)
+    } else if (!attn7_applies(Lq, Lk)) {
+        run(2, 0, Lq);           // few key tiles / few queries: the 4-wave kernel's shorter prologue and smaller blocks win (cross-attention)
     } else {
-        // 8-wave ping-pong kernel, one 256-query workgroup per CU. When its last round of workgroups would fill at most
-        // ~60 % of an XCD's 32 CUs, cut the query range: whole rounds on the 8-wave kernel, the remaining rows as 128-query
-        // workgroups of the 4-wave kernel, which then run one per CU.
-        const int64_t hx = (H + 7) / 8, nq4 = (Lq + QB4 - 1) / QB4;
-        const int64_t nb = hx * nq4, R = nb / 32, r = nb % 32;
-        const int64_t nq_main = R >= 1 ? (32 * R) / hx : 0;
-        if (r > 0 && r <= 20 && nq_main >= 1 && nq_main < nq4) {
-            run(4, 0, nq_main * QB4);
-            const int64_t lo = nq_main * QB4, rows = Lq - lo;
-            const int64_t need = 2 * rows * (H * D + H * 2) * 4;
-            const int64_t tail_blocks = hx * ((rows + QB - 1) / QB);
-            if (workspace && workspace_bytes >= need && tail_blocks <= 32 && Lk >= 4 * KT) {
-                // the tail is at most one 4-wave workgroup per CU: cut its key range in two so that two workgroups share a CU
-                // (as in the kernel's normal operating point) and each walks half the keys; merged in a fixed order
-                AttnArgs b = a;
-                b.q_lo = (int)lo;
-                b.nqb = (int)((rows + QB - 1) / QB);
-                b.part_o = reinterpret_cast<float*>(workspace);
-                b.part_ml = b.part_o + 2 * rows * H * D;
-                hipLaunchKernelGGL(attn_fwd_kernel_v2, dim3((unsigned)(hx * b.nqb * 8), 2), dim3(NW * 64), 0, st, b);
-                const int64_t nq = rows * H * (D / 4);
-                hipLaunchKernelGGL(attn_combine_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, st, b.part_o, b.part_ml, 2,
-                                   rows, (int)H, (unsigned short*)O, ldo, (int)lo, accumulate);
-            } else {
-                run(2, lo, Lq);
-            }
+        // one-wave-per-SIMD kernel, one 256-query workgroup per CU; the blocks of a partial last round are cut into key ranges
+        // when the caller gave the scratch for their partial results
+        const Plan7 pl = attn7_plan(Lq, Lk, H);
+        const int64_t rows = Lq - pl.tail_qb * QB4;
+        const int64_t need = pl.splits > 1 ? (int64_t)pl.splits * rows * (H * D + H * 2) * 4 : 0;
+        if (pl.splits > 1 && workspace && workspace_bytes >= need) {
+            AttnArgs b = a;
+            b.nqb = (int)((Lq + QB4 - 1) / QB4);
+            b.tail_qb = (int)pl.tail_qb;
+            b.splits = pl.splits;
+            b.part_o = reinterpret_cast<float*>(workspace);
+            b.part_ml = b.part_o + (int64_t)pl.splits * rows * H * D;
+            yume_attn7_launch(b, st);
+            const int64_t nq = rows * H * (D / 4);
+            hipLaunchKernelGGL(attn_combine_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, st, b.part_o, b.part_ml, pl.splits,
+                               rows, (int)H, (unsigned short*)O, ldo, (int)(pl.tail_qb * QB4), accumulate);
         } else {
-            run(4, 0, Lq);
+            run(7, 0, Lq);
         }
     }
     YUME_CHECK_LAUNCH("attn_fwd");

@@ -29,7 +29,13 @@
 #include "attn_args.hpp"
 #include <type_traits>
 
+#ifndef ATTN7_DBG
+#define ATTN7_DBG 0
+#endif
 namespace {
+// timing experiments only (results are garbage when non-zero): 1 no exp, 2 no fragment reads, 4 no DMA, 8 no softmax pieces,
+// 16 no barrier / vmcnt wait, 32 no row-sum adds, 64 no MFMAs, 128 no max pieces, 256 no packing
+constexpr int DBG = ATTN7_DBG;
 
 constexpr int KT = 64;
 constexpr int D = 128;
@@ -38,6 +44,10 @@ constexpr int NS = 4;                     // slots per operand
 constexpr int VB = NS * SLOT;             // V^T slots start here
 constexpr int LDS7 = 2 * NS * SLOT;       // 128 KiB
 constexpr int QB7 = 256;                  // queries per workgroup
+#ifndef ATTN7_RD
+#define ATTN7_RD 4
+#endif
+constexpr int RD = ATTN7_RD;              // fragment ring depth: a fragment is read RD MFMA gaps before its MFMA (power of two)
 constexpr float NEG_BIG = -1.0e30f;
 constexpr float DEFER_LOG2 = 8.0f;
 
@@ -51,10 +61,17 @@ constexpr int OA = 0, OB = 64, QA = 128, QB = 160;
 #define OWNED_AGPRS "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", AG8(1), AG8(2), AG8(3), AG8(4), AG8(5), AG8(6), AG8(7), \
     AG8(8), AG8(9), AG8(10), AG8(11), AG8(12), AG8(13), AG8(14), AG8(15), AG8(16), AG8(17), AG8(18), "a190", "a191"
 // S = K Q^T: D in VGPRs (the softmax reads it), A = K fragment (VGPR, from LDS), B = Q^T fragment a[q:q+3]
-#define MFMA_S0(d, a, q) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, a[%c2:%c3], 0" : "=&v"(d) : "v"(a), "n"(q), "n"((q) + 3) : "memory", OWNED_AGPRS)
-#define MFMA_S(d, a, q) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, a[%c2:%c3], %0" : "+v"(d) : "v"(a), "n"(q), "n"((q) + 3) : "memory", OWNED_AGPRS)
+// Every MFMA statement also names the softmax state of the OTHER block (Y) as input operands it does not use: that
+// pins the VALU work written in the preceding gap to that gap (LLVM otherwise sinks whatever is only needed after the
+// phase-end redo branch out from under the MFMAs) without separate statements — an empty asm right behind a VALU write
+// costs an s_nop each time.
+#define YPINS(y) "v"(y.z.x), "v"(y.z.p[0]), "v"(y.z.p[1]), "v"(y.z.p[2]), "v"(y.z.p[3]), "v"(y.z.p[4]), "v"(y.z.p[5]), "v"(y.z.p[6]), "v"(y.z.p[7]), \
+    "v"(y.z.sum0), "v"(y.z.sum1), "v"(y.z.mx), "v"(y.z.ev), "v"(y.z.od), "v"(y.z.w0), "v"(y.z.w1)
+#define MFMA_S0(d, a, q, y) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, a[%c2:%c3], 0" : "=&v"(d) : "v"(a), "n"(q), "n"((q) + 3), YPINS(y) : "memory", OWNED_AGPRS)
+#define MFMA_S(d, a, q, y) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, a[%c2:%c3], %0" : "+v"(d) : "v"(a), "n"(q), "n"((q) + 3), YPINS(y) : "memory", OWNED_AGPRS)
 // O += V^T P^T: C/D = a[o:o+15], A = V^T fragment (VGPR, from LDS), B = P^T fragment (VGPR)
-#define MFMA_O(o, a, b) asm volatile("v_mfma_f32_32x32x16_bf16 a[%c2:%c3], %0, %1, a[%c2:%c3]" ::"v"(a), "v"(b), "n"(o), "n"((o) + 15) : "memory", OWNED_AGPRS)
+#define MFMA_O(o, a, b, y) asm volatile("v_mfma_f32_32x32x16_bf16 a[%c2:%c3], %0, %1, a[%c2:%c3]" ::"v"(a), "v"(b), "n"(o), "n"((o) + 15), YPINS(y) : "memory", OWNED_AGPRS)
+#define PIN_BLK(y) asm volatile("" ::YPINS(y))
 template <int R>
 __device__ __forceinline__ void agpr_set(unsigned v) {
     asm volatile("v_accvgpr_write_b32 a[%c1], %0" ::"v"(v), "n"(R) : OWNED_AGPRS);
@@ -108,6 +125,8 @@ struct Soft {
     float p[8];         // exponentials not yet packed
     float sum0, sum1;   // partial row sums of the current tile
     float mx;           // max of the raw scores of the current tile
+    unsigned ev, od;    // packed pair waiting for its cross-half swap
+    unsigned w0, w1;    // the two P^T words the last swap produced (copies of what went into pf; only there to be pinned)
     float m_new;        // candidate exponent base
     float m_run;        // exponent base in use (log2 domain)
     float l_run;        // row sum over this lane's keys
@@ -123,47 +142,49 @@ struct Blk {             // the compiler-managed part of a block (O^T and Q^T ar
 //   I = e      : x_e = s_e * c - m                          (I = 0..31)
 //   I = e + 1  : p_e = exp2(x_e)  [masked]                   (I = 1..32)
 //   I = e + 2  : row sum                                     (I = 2..33)
-//   I = 8g + 9, 8g + 10 : pack the 8 exponentials of group g into the P^T fragment g (2 cvt_pk + 1 permlane32_swap each)
+//   I = 8g + 9 .. 8g + 11 : pack the 8 exponentials of group g into the P^T fragment g: cvt_pk pair 0 | swap 0, cvt_pk pair 1 |
+//                swap 1 (a v_permlane32_swap right behind the cvt_pk that feeds it needs two idle states)
 //   I = 0..15  : running max of the raw scores, I = 16 cross-half, I = 17 candidate base + wave vote
-//   I = 34     : l += sums
-// Pieces 0..31 sit in the 32 MFMA gaps of the phase that computes the OTHER block; 32..34 ("drain") sit in the first three
+//   I = 35     : l += sums
+// Pieces 0..31 sit in the 32 MFMA gaps of the phase that computes the OTHER block; 32..35 ("drain") sit in the first four
 // gaps of the next phase. Re-running pieces 0..31 rebuilds exactly the state the drain expects (the redo path).
 template <int I, bool MASK>
 __device__ __forceinline__ void sm_piece(Soft& z, const f32x16 (&s)[2], u32x4 (&pf)[4], float c, int keyb, int Lk) {
-    if constexpr (I >= 2 && I <= 33) {
+    if constexpr (I >= 2 && I <= 33 && !(DBG & 32)) {
         constexpr int e = I - 2;
         if constexpr (e == 0) z.sum0 = z.p[0];
         else if constexpr (e == 1) z.sum1 = z.p[1];
-        else if constexpr ((e & 1) != 0) { z.sum1 += z.p[e & 7]; PIN(z.sum1); }
-        else { z.sum0 += z.p[e & 7]; PIN(z.sum0); }
+        else if constexpr ((e & 1) != 0) z.sum1 += z.p[e & 7];
+        else z.sum0 += z.p[e & 7];
     }
-    if constexpr (I >= 9 && (((I - 9) & 7) < 2)) {
-        constexpr int g = (I - 9) >> 3, i = (I - 9) & 7;
-        const unsigned ev = pack_bf16x2(z.p[2 * i], z.p[2 * i + 1]);
-        const unsigned od = pack_bf16x2(z.p[4 + 2 * i], z.p[4 + 2 * i + 1]);
-        const auto r = __builtin_amdgcn_permlane32_swap(ev, od, false, false);
-        unsigned w0 = r[0], w1 = r[1];
-        PIN(w0);
-        PIN(w1);
-        pf[g][i] = w0;
-        pf[g][2 + i] = w1;
+    if constexpr (I >= 9 && !(DBG & 256)) {
+        constexpr int g = (I - 9) >> 3, k = (I - 9) & 7;
+        if constexpr (k == 1 || k == 2) {          // swap of pair k - 1
+            const auto r = __builtin_amdgcn_permlane32_swap(z.ev, z.od, false, false);
+            z.w0 = r[0];
+            z.w1 = r[1];
+            pf[g][k - 1] = z.w0;
+            pf[g][2 + k - 1] = z.w1;
+            if constexpr (k == 2) { z.ev = z.w0; z.od = z.w1; }   // nothing stale stays live as a pin (the swap works in place)
+        }
+        if constexpr (k == 0 || k == 1) {          // cvt_pk of pair k
+            z.ev = pack_bf16x2(z.p[2 * k], z.p[2 * k + 1]);
+            z.od = pack_bf16x2(z.p[4 + 2 * k], z.p[4 + 2 * k + 1]);
+        }
     }
     if constexpr (I >= 1 && I <= 32) {
         constexpr int e = I - 1;
-        float pv = __builtin_amdgcn_exp2f(z.x);
+        float pv = (DBG & 1) ? z.x : __builtin_amdgcn_exp2f(z.x);
         if constexpr (MASK) {
             constexpr int b = e >> 4, r = e & 15;
             const int key = keyb + 32 * b + (r & 3) + 8 * (r >> 2);
             pv = key < Lk ? pv : 0.f;
         }
-        PIN(pv);
         z.p[e & 7] = pv;
     }
-    if constexpr (I <= 31) {
-        z.x = __builtin_fmaf(s[I >> 4][I & 15], c, -z.m_run);
-        PIN(z.x);
-    }
-    if constexpr (I == 0) {
+    if constexpr (I <= 31) z.x = __builtin_fmaf(s[I >> 4][I & 15], c, -z.m_run);
+    if constexpr (DBG & 128) {
+    } else if constexpr (I == 0) {
         z.mx = max2f(s[0][0], s[0][1]);
     } else if constexpr (I <= 15) {
         constexpr int e = 2 * I;
@@ -174,8 +195,7 @@ __device__ __forceinline__ void sm_piece(Soft& z, const f32x16 (&s)[2], u32x4 (&
         z.m_new = max2f(z.m_run, z.mx * c);
         z.need = !__all(z.m_new - z.m_run <= DEFER_LOG2);
     }
-    if constexpr (I <= 16) PIN(z.mx);
-    if constexpr (I == 34) { z.l_run += z.sum0 + z.sum1; PIN(z.l_run); }
+    if constexpr (I == 35) z.l_run += z.sum0 + z.sum1;
 }
 
 #define REP32(M) M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7) M(8) M(9) M(10) M(11) M(12) M(13) M(14) M(15) \
@@ -307,10 +327,10 @@ __device__ __forceinline__ u32x4 frag(const Ctx& cx, int kb, int vb) {
 // X (O^T at a[XO..], Q^T at a[XQ..]): the block whose MFMAs run (S of the tile in K slot kb if DO_S, O += V^T P of the tile in V slot vb if DO_PV) and whose
 //    previous softmax drains in the first gaps (DRAIN, tile starting at key jx);
 // Y (O^T at a[YO..]): the block whose softmax pieces fill the gaps (SM, tile starting at key jy).
-// CIN: ring[0..3] already hold this phase's first four fragments; COUT: the last four gaps fetch K fragments 0..3 of slot nkb.
+// CIN: the ring already holds this phase's first RD fragments; COUT: the last RD gaps fetch K fragments 0..RD-1 of slot nkb.
 // DMA: gaps 0..7 issue one LDS-DMA piece each (K tile at kg -> kslot, V^T tile at vg -> vslot).
 template <int XO, int XQ, int YO, bool DO_S, bool DO_PV, bool DRAIN, bool MASKX, bool SM, bool MASKY, bool DMA, bool CIN, bool COUT>
-__device__ __forceinline__ void phase(const Ctx& cx, Blk& X, Blk& Y, u32x4 (&ring)[4], int kb, int vb, int nkb, int jx, int jy,
+__device__ __forceinline__ void phase(const Ctx& cx, Blk& X, Blk& Y, u32x4 (&ring)[RD], int kb, int vb, int nkb, int jx, int jy,
                                       const Dma7& dp, const char* kg, const char* vg, unsigned kslot, unsigned vslot) {
     constexpr int F0 = DO_S ? 0 : 16;
     if constexpr (!CIN && (DO_S || DO_PV)) {
@@ -318,31 +338,40 @@ __device__ __forceinline__ void phase(const Ctx& cx, Blk& X, Blk& Y, u32x4 (&rin
         ring[1] = frag<F0 + 1>(cx, kb, vb);
         ring[2] = frag<F0 + 2>(cx, kb, vb);
         ring[3] = frag<F0 + 3>(cx, kb, vb);
+        if constexpr (RD == 8) {
+            ring[4] = frag<F0 + 4>(cx, kb, vb);
+            ring[5] = frag<F0 + 5>(cx, kb, vb);
+            ring[6] = frag<F0 + 6>(cx, kb, vb);
+            ring[7] = frag<F0 + 7>(cx, kb, vb);
+        }
     }
     __builtin_amdgcn_sched_barrier(0);
 #define YUME_GAP(i)                                                                                          \
     {                                                                                                        \
+        if constexpr (SM && ((i) < 16 ? !DO_S : !DO_PV)) PIN_BLK(Y);                                         \
         if constexpr ((i) < 16) {                                                                            \
-            if constexpr (DO_S) {                                                                            \
-                if constexpr (((i) >> 1) == 0) MFMA_S0(X.s[(i) & 1], ring[(i) & 3], XQ);                 \
-                else MFMA_S(X.s[(i) & 1], ring[(i) & 3], XQ + 4 * ((i) >> 1));                                     \
+            if constexpr (DO_S && !(DBG & 64)) {                                                             \
+                if constexpr (((i) >> 1) == 0) MFMA_S0(X.s[(i) & 1], ring[(i) & (RD - 1)], XQ, Y);                 \
+                else MFMA_S(X.s[(i) & 1], ring[(i) & (RD - 1)], XQ + 4 * ((i) >> 1), Y);                                     \
             }                                                                                                \
-        } else if constexpr (DO_PV) {                                                                        \
-            MFMA_O(XO + 16 * (((i) - 16) & 3), ring[(i) & 3], X.pf[((i) - 16) >> 2]);                               \
+        } else if constexpr (DO_PV && !(DBG & 64)) {                                                         \
+            MFMA_O(XO + 16 * (((i) - 16) & 3), ring[(i) & (RD - 1)], X.pf[((i) - 16) >> 2], Y);                               \
         }                                                                                                    \
-        if constexpr ((i) + 4 < 32) {                                                                        \
-            if constexpr ((i) + 4 >= 16 ? DO_PV : DO_S) ring[(i) & 3] = frag<((i) + 4) & 31>(cx, kb, vb);    \
-        } else if constexpr (COUT) {                                                                         \
-            ring[(i) & 3] = frag<((i) + 4) & 15>(cx, nkb, 0);                                                \
+        if constexpr ((i) + RD < 32) {                                                                       \
+            if constexpr (((i) + RD >= 16 ? DO_PV : DO_S) && !(DBG & 2)) ring[(i) & (RD - 1)] = frag<((i) + RD) & 31>(cx, kb, vb); \
+        } else if constexpr (COUT && !(DBG & 2)) {                                                           \
+            ring[(i) & (RD - 1)] = frag<((i) + RD) & 15>(cx, nkb, 0);                                        \
         }                                                                                                    \
-        if constexpr (DMA && (i) < 8) dma7_piece<(i) & 7>(dp, kg, vg, kslot, vslot, cx.wave);                \
-        if constexpr (DRAIN && (i) < 3) sm_piece<32 + ((i) & 3), MASKX>(X.z, X.s, X.pf, cx.c, jx + cx.keyh, cx.Lk); \
-        if constexpr (SM) sm_piece<(i), MASKY>(Y.z, Y.s, Y.pf, cx.c, jy + cx.keyh, cx.Lk);                   \
+        if constexpr (DMA && (i) < 8 && !(DBG & 4)) dma7_piece<(i) & 7>(dp, kg, vg, kslot, vslot, cx.wave);                \
+        if constexpr (DRAIN && (i) >= 1 && (i) < 5 && !(DBG & 8)) PIN_BLK(X);     /* drain piece of the previous gap stays there */ \
+        if constexpr (DRAIN && (i) < 4 && !(DBG & 8)) sm_piece<32 + ((i) & 3), MASKX>(X.z, X.s, X.pf, cx.c, jx + cx.keyh, cx.Lk); \
+        if constexpr (SM && !(DBG & 8)) sm_piece<(i), MASKY>(Y.z, Y.s, Y.pf, cx.c, jy + cx.keyh, cx.Lk);                   \
         __builtin_amdgcn_sched_barrier(0);                                                                   \
     }
     REP32(YUME_GAP)
 #undef YUME_GAP
     if constexpr (SM) {
+        PIN_BLK(Y);
         if (__builtin_expect(Y.z.need, 0)) redo_tile<YO, MASKY>(Y, cx.c, jy + cx.keyh, cx.Lk);
     }
 }
@@ -393,6 +422,7 @@ __device__ __forceinline__ void load_q(const AttnArgs& p, Blk& x, int q, int h, 
     x.z.sum0 = x.z.sum1 = 0.f;
     x.z.x = 0.f;
     x.z.mx = 0.f;
+    x.z.ev = x.z.od = x.z.w0 = x.z.w1 = 0u;
     x.z.m_new = NEG_BIG;
 #pragma unroll
     for (int i = 0; i < 8; ++i) x.z.p[i] = 0.f;
@@ -400,35 +430,61 @@ __device__ __forceinline__ void load_q(const AttnArgs& p, Blk& x, int q, int h, 
 
 // steady-state tile t (TS = t % 4): 1 <= t, t + 4 < number of FULL tiles; every LDS address is a compile-time constant
 template <int TS>
-__device__ __forceinline__ void steady7(const Ctx& cx, const Dma7& dp, int t, Blk& A, Blk& B, u32x4 (&ring)[4]) {
+__device__ __forceinline__ void steady7(const Ctx& cx, const Dma7& dp, int t, Blk& A, Blk& B, u32x4 (&ring)[RD]) {
     constexpr int kb = ((TS + 1) & 3) * SLOT, vb = TS * SLOT, nkb = ((TS + 2) & 3) * SLOT;
     const char* kg = dp.kbase + (int64_t)(t + 4) * KT * dp.krow;
     const char* vg = dp.vbase + (int64_t)(t + 3) * KT * 2;
     const unsigned kslot = cx.lds0 + TS * SLOT;
     const unsigned vslot = cx.lds0 + VB + ((TS + 3) & 3) * SLOT;
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");      // everything older than the previous tile's 8 pieces has landed
-    __builtin_amdgcn_s_barrier();
+    if constexpr (!(DBG & 16)) {
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");      // everything older than the previous tile's 8 pieces has landed
+        __builtin_amdgcn_s_barrier();
+    }
     phase<OA, QA, OB, true, true, true, false, true, false, true, true, true>(cx, A, B, ring, kb, vb, kb, 0, 0, dp, kg, vg, kslot, vslot);
     phase<OB, QB, OA, true, true, true, false, true, false, false, true, true>(cx, B, A, ring, kb, vb, nkb, 0, 0, dp, kg, vg, kslot, vslot);
 }
 
-// any tile t (runtime slots; the softmax pieces always carry the key mask)
-__device__ __forceinline__ void general7(const Ctx& cx, const Dma7& dp, const AttnArgs& p, int t, int nt, bool ragged, int tid,
-                                         Blk& A, Blk& B, u32x4 (&ring)[4]) {
+// any tile t of the range [.., t1) (runtime slots; the softmax pieces always carry the key mask). nt / ragged describe the whole key
+// sequence: only its last tile can be ragged.
+__device__ __forceinline__ void general7(const Ctx& cx, const Dma7& dp, const AttnArgs& p, int t, int t0, int t1, int nt, bool ragged, int tid,
+                                         Blk& A, Blk& B, u32x4 (&ring)[RD]) {
     const int last = nt - 1;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (ragged && t == (last >= 2 ? last - 2 : 0) && last >= 3) fix7_v(dp, p, last, cx.smem + VB + (last & 3) * SLOT, tid);
+    // V^T(last) was issued three tiles ago (or in the prologue): zero its keys >= Lk before the barrier that precedes its first read
+    if (ragged && t1 == nt && t == (last - 2 > t0 ? last - 2 : t0)) fix7_v(dp, p, last, cx.smem + VB + (last & 3) * SLOT, tid);
     __builtin_amdgcn_s_barrier();
-    if (t + 4 < nt) dma7_k(dp, p, t + 4, ragged && t + 4 == last, cx.lds0 + ((t + 4) & 3) * SLOT, cx.wave);
-    if (t + 3 < nt) dma7_v(dp, p, t + 3, ragged && t + 3 == last, cx.lds0 + VB + ((t + 3) & 3) * SLOT, cx.wave);
+    if (t + 4 < t1) dma7_k(dp, p, t + 4, ragged && t + 4 == last, cx.lds0 + ((t + 4) & 3) * SLOT, cx.wave);
+    if (t + 3 < t1) dma7_v(dp, p, t + 3, ragged && t + 3 == last, cx.lds0 + VB + ((t + 3) & 3) * SLOT, cx.wave);
     const int kb = ((t + 1) & 3) * SLOT, vb = (t & 3) * SLOT;
     const int j = t * KT;
-    if (t + 1 < nt) {
+    if (t + 1 < t1) {
         phase<OA, QA, OB, true, true, true, true, true, true, false, false, false>(cx, A, B, ring, kb, vb, 0, j, j, dp, nullptr, nullptr, 0u, 0u);
         phase<OB, QB, OA, true, true, true, true, true, true, false, false, false>(cx, B, A, ring, kb, vb, 0, j, j + KT, dp, nullptr, nullptr, 0u, 0u);
     } else {
         phase<OA, QA, OB, false, true, true, true, true, true, false, false, false>(cx, A, B, ring, kb, vb, 0, j, j, dp, nullptr, nullptr, 0u, 0u);
         phase<OB, QB, OA, false, true, true, true, false, true, false, false, false>(cx, B, A, ring, kb, vb, 0, j, j, dp, nullptr, nullptr, 0u, 0u);
+    }
+}
+
+// unnormalised O^T, running base and row sum of one key range -> the scratch attn_combine_kernel merges (layout: attn_args.hpp)
+template <int XO>
+__device__ __forceinline__ void store_partial(const AttnArgs& p, const Blk& x, int q, int h, int hi, int sp, int64_t rows, int row0) {
+    const float l_part = xhalf_sum(x.z.l_run);
+    float o[64];
+    for_regs<0, 64>([&](auto r) { o[decltype(r)::value] = agpr_get<XO + decltype(r)::value>(); });
+    if (q < p.Lq) {
+        const int64_t r = q - row0;
+        float* po = p.part_o + ((int64_t)sp * rows + r) * ((int64_t)p.H * D) + h * D + 4 * hi;
+#pragma unroll
+        for (int db = 0; db < 4; ++db)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                *reinterpret_cast<f32x4*>(po + 32 * db + 8 * g) = f32x4{o[16 * db + 4 * g + 0], o[16 * db + 4 * g + 1], o[16 * db + 4 * g + 2], o[16 * db + 4 * g + 3]};
+        if (hi == 0) {
+            float* pm = p.part_ml + (((int64_t)sp * rows + r) * p.H + h) * 2;
+            pm[0] = x.z.m_run;
+            pm[1] = l_part;
+        }
     }
 }
 
@@ -439,16 +495,29 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_kernel_v7(AttnArgs p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int hi = lane >> 5;
     const int ql = lane & 31;
-    int h, qb;
+    const int nt = (p.Lk + KT - 1) / KT;
+    // block -> (head, query block[, key range]): XCD x (= blockIdx % 8) owns heads x, x+8, ...; its whole blocks come first, then the
+    // key-range pieces of the blocks >= tail_qb (hardware dispatches block ids in order: the pieces fill the last, partial round)
+    int h, qb, sp = 0, nsp = 1;
     {
         const int bid = blockIdx.x;
         const int xcd = bid & 7, idx = bid >> 3;
         const int hx = (p.H + 7 - xcd) >> 3;
-        const int per = hx * p.nqb;
-        if (idx >= per) return;
-        h = xcd + 8 * (idx / p.nqb);
-        qb = idx % p.nqb;
+        const int nmain = hx * p.tail_qb, ntq = p.nqb - p.tail_qb;
+        if (idx < nmain) {
+            h = xcd + 8 * (idx / p.tail_qb);
+            qb = idx % p.tail_qb;
+        } else {
+            const int j = idx - nmain;
+            if (j >= hx * ntq * p.splits) return;
+            const int u = j / p.splits;
+            sp = j % p.splits;
+            nsp = p.splits;
+            h = xcd + 8 * (u / ntq);
+            qb = p.tail_qb + u % ntq;
+        }
     }
+    const int t0 = (int)((int64_t)nt * sp / nsp), t1 = (int)((int64_t)nt * (sp + 1) / nsp);
     const int q0 = p.q_lo + qb * QB7 + wave * 64;
 
     Ctx cx;
@@ -465,65 +534,82 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_kernel_v7(AttnArgs p) {
 
     Dma7 dp;
     dma7_init(dp, p, h, tid);
-    const int nt = (p.Lk + KT - 1) / KT;
     const bool ragged = (p.Lk % KT) != 0;
-    const int nfull = ragged ? nt - 1 : nt;
     const int last = nt - 1;
+    const int tsteady = (ragged && t1 == nt) ? t1 - 1 : t1;      // tiles below this index are full AND inside the range
 
     Blk A, B;
     load_q<OA, QA>(p, A, q0 + ql, h, hi);
     load_q<OB, QB>(p, B, q0 + 32 + ql, h, hi);
     __builtin_amdgcn_sched_barrier(0);
-    // ---- prologue DMA: K(0) | K(1) V(0) | K(2) V(1) | K(3) V(2) ----
-    dma7_k(dp, p, 0, ragged && last == 0, cx.lds0, wave);
-    if (nt > 1) dma7_k(dp, p, 1, ragged && last == 1, cx.lds0 + SLOT, wave);
-    dma7_v(dp, p, 0, ragged && last == 0, cx.lds0 + VB, wave);
-    if (nt > 2) dma7_k(dp, p, 2, ragged && last == 2, cx.lds0 + 2 * SLOT, wave);
-    if (nt > 1) dma7_v(dp, p, 1, ragged && last == 1, cx.lds0 + VB + SLOT, wave);
-    if (nt > 3) dma7_k(dp, p, 3, ragged && last == 3, cx.lds0 + 3 * SLOT, wave);
-    if (nt > 2) dma7_v(dp, p, 2, ragged && last == 2, cx.lds0 + VB + 2 * SLOT, wave);
+    // ---- prologue DMA: K(t0) | K(t0+1) V(t0) | K(t0+2) V(t0+1) | K(t0+3) V(t0+2) ----
+    dma7_k(dp, p, t0, ragged && last == t0, cx.lds0 + (t0 & 3) * SLOT, wave);
+    if (t0 + 1 < t1) dma7_k(dp, p, t0 + 1, ragged && last == t0 + 1, cx.lds0 + ((t0 + 1) & 3) * SLOT, wave);
+    dma7_v(dp, p, t0, ragged && last == t0, cx.lds0 + VB + (t0 & 3) * SLOT, wave);
+    if (t0 + 2 < t1) dma7_k(dp, p, t0 + 2, ragged && last == t0 + 2, cx.lds0 + ((t0 + 2) & 3) * SLOT, wave);
+    if (t0 + 1 < t1) dma7_v(dp, p, t0 + 1, ragged && last == t0 + 1, cx.lds0 + VB + ((t0 + 1) & 3) * SLOT, wave);
+    if (t0 + 3 < t1) dma7_k(dp, p, t0 + 3, ragged && last == t0 + 3, cx.lds0 + ((t0 + 3) & 3) * SLOT, wave);
+    if (t0 + 2 < t1) dma7_v(dp, p, t0 + 2, ragged && last == t0 + 2, cx.lds0 + VB + ((t0 + 2) & 3) * SLOT, wave);
 
     __builtin_amdgcn_sched_barrier(0);
-    if (nt > 3) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");      // K(0) has landed (Q loads are older still)
-    else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (ragged && last <= 2) fix7_v(dp, p, last, smem + VB + last * SLOT, tid);
-    }
+    if (t0 + 3 < t1) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");      // K(t0) has landed (the Q loads are older still)
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     NOP_PAD();
 
-    u32x4 ring[4];
-    // S_A(0), then S_B(0) beside softmax_A(0)
-    phase<OA, QA, OB, true, false, false, true, false, true, false, false, false>(cx, A, B, ring, 0, 0, 0, 0, 0, dp, nullptr, nullptr, 0u, 0u);
-    phase<OB, QB, OA, true, false, false, true, true, true, false, false, false>(cx, B, A, ring, 0, 0, 0, 0, 0, dp, nullptr, nullptr, 0u, 0u);
+    u32x4 ring[RD];
+    // S_A(t0), then S_B(t0) beside softmax_A(t0)
+    {
+        const int kb0 = (t0 & 3) * SLOT, j0 = t0 * KT;
+        phase<OA, QA, OB, true, false, false, true, false, true, false, false, false>(cx, A, B, ring, kb0, 0, 0, j0, j0, dp, nullptr, nullptr, 0u, 0u);
+        phase<OB, QB, OA, true, false, false, true, true, true, false, false, false>(cx, B, A, ring, kb0, 0, 0, j0, j0, dp, nullptr, nullptr, 0u, 0u);
+    }
 
-    general7(cx, dp, p, 0, nt, ragged, tid, A, B, ring);
-    int t = 1;
-    if (t + 7 < nfull) {
-        // first four fragments of phase 1(1): K(2), published by the barrier of tile 0
-        ring[0] = frag<0>(cx, 2 * SLOT, 0);
-        ring[1] = frag<1>(cx, 2 * SLOT, 0);
-        ring[2] = frag<2>(cx, 2 * SLOT, 0);
-        ring[3] = frag<3>(cx, 2 * SLOT, 0);
+    int t = t0;
 #pragma unroll 1
-        for (; t + 7 < nfull; t += 4) {        // t % 4 == 1; the four calls issue tiles up to t + 7 (all full)
-            steady7<1>(cx, dp, t, A, B, ring);
-            steady7<2>(cx, dp, t + 1, A, B, ring);
-            steady7<3>(cx, dp, t + 2, A, B, ring);
-            steady7<0>(cx, dp, t + 3, A, B, ring);
+    while (t < t1) {
+        if (t > t0 && (t & 3) == 1 && t + 7 < tsteady) {
+            // first fragments of phase 1(t): K(t+1) in slot 2, published by the barrier of the previous tile
+            ring[0] = frag<0>(cx, 2 * SLOT, 0);
+            ring[1] = frag<1>(cx, 2 * SLOT, 0);
+            ring[2] = frag<2>(cx, 2 * SLOT, 0);
+            ring[3] = frag<3>(cx, 2 * SLOT, 0);
+            if constexpr (RD == 8) {
+                ring[4] = frag<4>(cx, 2 * SLOT, 0);
+                ring[5] = frag<5>(cx, 2 * SLOT, 0);
+                ring[6] = frag<6>(cx, 2 * SLOT, 0);
+                ring[7] = frag<7>(cx, 2 * SLOT, 0);
+            }
+#pragma unroll 1
+            for (; t + 7 < tsteady; t += 4) {        // t % 4 == 1; the four calls issue tiles up to t + 7 (all full, all in range)
+                steady7<1>(cx, dp, t, A, B, ring);
+                steady7<2>(cx, dp, t + 1, A, B, ring);
+                steady7<3>(cx, dp, t + 2, A, B, ring);
+                steady7<0>(cx, dp, t + 3, A, B, ring);
+            }
+        } else {
+            general7(cx, dp, p, t, t0, t1, nt, ragged, tid, A, B, ring);
+            ++t;
         }
     }
-#pragma unroll 1
-    for (; t < nt; ++t) general7(cx, dp, p, t, nt, ragged, tid, A, B, ring);
 
     NOP_PAD();
-    store_block<OA>(p, A, q0 + ql, h, hi);
-    store_block<OB>(p, B, q0 + 32 + ql, h, hi);
+    if (nsp > 1) {
+        const int row0 = p.q_lo + p.tail_qb * QB7;
+        const int64_t rows = p.Lq - row0;
+        store_partial<OA>(p, A, q0 + ql, h, hi, sp, rows, row0);
+        store_partial<OB>(p, B, q0 + 32 + ql, h, hi, sp, rows, row0);
+    } else {
+        store_block<OA>(p, A, q0 + ql, h, hi);
+        store_block<OB>(p, B, q0 + 32 + ql, h, hi);
+    }
 }
 
 }  // namespace
 
 void yume_attn7_launch(const AttnArgs& a, hipStream_t st) {
-    const dim3 grid((unsigned)(((a.H + 7) / 8) * a.nqb * 8));
+    // every XCD slot gets ceil(H/8) * (whole blocks + pieces) block ids; surplus ids exit immediately
+    const int64_t per = (int64_t)a.tail_qb + (int64_t)(a.nqb - a.tail_qb) * a.splits;
+    const dim3 grid((unsigned)(((a.H + 7) / 8) * per * 8));
     hipLaunchKernelGGL(attn_fwd_kernel_v7, grid, dim3(256), 0, st, a);
 }

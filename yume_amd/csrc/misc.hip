@@ -15,7 +15,7 @@ void yume_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* yume_last_error(void) { return g_err; }
-extern "C" int yume_abi_version(void) { return 1; }
+extern "C" int yume_abi_version(void) { return YUME_ABI_VERSION; }
 extern "C" const char* yume_target_arch(void) { return "gfx950"; }
 
 namespace {

@@ -70,7 +70,13 @@ def gemm_bf16(a, w, bias, out, epi=EPI_BF16, gate=None, gate_stride=0, row_idx=N
     return out
 
 
+# Scratch buffers of the split-K GEMM and the attention key-range split are keyed by (device, stream): two callers on
+# different HIP streams of one device (a VAE decode overlapped with the next chunk's denoise, say) never share partials.
 _splitk_ws = {}
+
+
+def _ws_key(t):
+    return (t.device.index, _stream())
 
 
 def gemm_small_m(a, w, bias, out, epi=EPI_BF16, target_blocks=256):
@@ -91,7 +97,7 @@ def gemm_small_m(a, w, bias, out, epi=EPI_BF16, target_blocks=256):
     wp, ldw = _rows(w, "w")
     op, ldo = _rows(out, "out")
     need = splits * M * N
-    key = a.device.index
+    key = _ws_key(a)
     ws = _splitk_ws.get(key)
     if ws is None or ws.numel() < need:
         ws = torch.empty(max(need, 1 << 22), dtype=torch.float32, device=a.device)
@@ -145,9 +151,10 @@ def attn_fwd(q, k, vt, out, Lq, Lk, H, scale=None, accumulate=False, variant=0, 
         if nbytes is None:
             nbytes = _attn_ws_bytes[key] = int(lib.yume_attn_workspace_bytes(Lq, Lk, H))
         if nbytes:
-            ws = _attn_ws.get(q.device.index)
+            wkey = _ws_key(q)
+            ws = _attn_ws.get(wkey)
             if ws is None or ws.numel() < nbytes:
-                ws = _attn_ws[q.device.index] = torch.empty(nbytes, dtype=torch.uint8, device=q.device)
+                ws = _attn_ws[wkey] = torch.empty(nbytes, dtype=torch.uint8, device=q.device)
     rc = lib.yume_attn_fwd_ws(qp, ldq, kp, ldk, vp, ldv, op, ldo, Lq, Lk, H, scale, 1 if accumulate else 0, variant,
                               _ptr(ws), nbytes if ws is not None else 0, _stream())
     _lib.check(rc, "yume_attn_fwd")
