@@ -233,7 +233,7 @@ def test_attention_auto_splits_query_range_between_kernels():
         assert (got.float() - want.float()).abs().max() <= 2.0 ** -6 * want.float().abs().max()
     # the tail rows went through the key-range split (two partial softmaxes merged): same function as the unsplit call
     qd, kd = q.to(DEV), k.to(DEV)
-    vt = torch.zeros(H * 128, Lk, dtype=torch.bfloat16, device=DEV)
+    vt = torch.zeros(H * 128, (Lk + 7) // 8 * 8, dtype=torch.bfloat16, device=DEV)
     ops.transpose_bf16(v.to(DEV), vt)
     o_ws = torch.empty(Lq, H * 128, dtype=torch.bfloat16, device=DEV)
     o_no = torch.empty_like(o_ws)
