@@ -14,10 +14,15 @@ Multi-GPU: every rank runs its own independent chain (its own prompt/noise), exa
 value = total steps of all ranks / max-over-ranks time.
 
 The JSON line also carries
-  roofline     : the dominant kernel (ffn.0 bf16 MFMA GEMM, 9460x14336x3072) timed with HIP events on the launch
-                 stream inside the timed steps, against the 2.5 PFLOP/s dense bf16 MFMA peak.
+  roofline     : the kernel with the LARGEST share of the timed steps (every kernel group of the block is bracketed with HIP
+                 events on the launch stream inside the timed region; today that is the self-attention kernel), against the
+                 2.5 PFLOP/s dense bf16 MFMA peak; roofline_all lists the other groups the same way.
   cpu_baseline : the CPU oracle restatement of the reference (oracle/dit.py) timed on the host cores on a bounded
                  sample (one DiT block at the full L, extrapolated to 30 blocks), rank 0 / N=1 only.
+  parity       : that same CPU block output against the device engine on identical inputs (rel-L2 / max-abs).
+  vae_decode   : Wan2.2 decode latents/s on the GPU and the oracle VAE on the host cores (reduced size, FLOP-scaled).
+
+--workload tts / longvideo / 14b run BASELINE.json configs[3] / [4] / [2] (see their functions); the default is configs[1].
 """
 import argparse
 import json
@@ -40,18 +45,33 @@ def flops_fwd_5b(L, C=3072, ffn=14336, n=30, Lc=512, cin=48, cout=48):
     return n * blk + 2 * L * (cin * 4) * C + 2 * 512 * (4096 * C + C * C) + 2 * L * (256 * C + C * C + 6 * C * C) + 2 * L * C * 4 * cout
 
 
-def pmc_traffic_bytes():
-    """HBM/fabric bytes per launch of the dominant kernel from the committed rocprofv3 PMC pass
-    (profiles/r1_pmc_dominant_kernels.csv: FETCH_SIZE and WRITE_SIZE in KiB; FETCH_SIZE doubled per the gfx950
-    calibration in MI355X_MICROARCH.md, confirmed on the adaLN kernel: 2*FETCH = 4*L*C exactly)."""
+PMC_FILES = ("r2_pmc_dominant_kernels.csv", "r1_pmc_dominant_kernels.csv")
+PMC_KERNEL_OF_GROUP = {"attn_self": ("attn_fwd_kernel_v7", "attn_combine_kernel"), "gemm_ffn0": ("gemm256_kernel<1",),
+                       "gemm_ffn2": ("gemm256_kernel<3",), "gemm_o": ("gemm256_kernel<3",), "gemm_cross_o": ("gemm256_kernel<3",)}
+
+
+def pmc_traffic_bytes(group):
+    """HBM/fabric bytes per launch of a kernel group from the committed rocprofv3 PMC passes (profiles/*_pmc_dominant_kernels.csv:
+    FETCH_SIZE and WRITE_SIZE in KiB; FETCH_SIZE doubled per the gfx950 calibration in MI355X_MICROARCH.md, confirmed on the
+    adaLN kernel: 2*FETCH = 4*L*C exactly). None when no pass of that kernel is committed."""
     import csv
-    path = os.path.join(ROOT, "profiles", "r1_pmc_dominant_kernels.csv")
-    try:
-        for r in csv.DictReader(open(path)):
-            if "gemm256_kernel<1" in r["kernel"]:
-                return (2.0 * float(r["FETCH_SIZE"]) + float(r["WRITE_SIZE"])) * 1024.0
-    except Exception:  # noqa: BLE001
-        pass
+    names = PMC_KERNEL_OF_GROUP.get(group)
+    if not names:
+        return None
+    for f in PMC_FILES:
+        try:
+            rows = list(csv.DictReader(open(os.path.join(ROOT, "profiles", f))))
+        except Exception:  # noqa: BLE001
+            continue
+        tot, hit = 0.0, False
+        for n in names:
+            for r in rows:
+                if n in r["kernel"] and r.get("FETCH_SIZE") and r.get("WRITE_SIZE"):
+                    tot += (2.0 * float(r["FETCH_SIZE"]) + float(r["WRITE_SIZE"])) * 1024.0
+                    hit = True
+                    break
+        if hit:
+            return tot
     return None
 
 
@@ -84,38 +104,207 @@ def vae_decode_rate(dev, z8):
             "tflop_per_chunk": 485.04, "tflops": 485.04 / dt}
 
 
-def cpu_baseline(cfg, L, n_hist, seconds_budget=30.0):
-    """Reference restatement on the host cores: one full-width block at the full sequence length."""
-    from oracle import dit as odit
+def vae_cpu_baseline():
+    """north_star: "VAE decode latents/sec, vs CPU reference". The oracle decoder (oracle/vae.py, fp32, pinned to the reference) on
+    the host cores at a reduced spatial size — 2 latents [48,2,16,24] instead of [48,8,44,80] — with its FLOPs counted by torch's
+    FlopCounterMode; the full-size rate is that FLOP rate divided by the 485.04/8 TFLOP one full-size latent costs."""
+    from torch.utils.flop_counter import FlopCounterMode
+    from oracle import vae as ovae
     from yume_amd import synth
     torch.set_num_threads(os.cpu_count() or 1)
-    c1 = dict(cfg)
-    c1["num_layers"] = 1
-    sd = {k: v for k, v in synth.make_dit_state_dict(c1, "wan23", seed=0, pyramid=()).items() if k.startswith("blocks.0.")}
-    C = cfg["dim"]
-    g = torch.Generator().manual_seed(0)
-    x = torch.randn(L, C, generator=g)
-    e6 = torch.randn(L, 6, C, generator=g) * 0.1
-    ctx = torch.randn(512, C, generator=g)
-    tabs = odit.rope_axes(128)
-    rope = odit.rope_grid(tabs, 1, 1, L, 0) if L <= 1024 else torch.polar(torch.ones(L, 64, dtype=torch.float64),
-                                                                           torch.randn(L, 64, generator=g).double())
-    # fp32 attention for the timing leg (the fp64 exact-softmax of the parity oracle would dominate the CPU time)
-    orig = odit.attention
-
-    def attn32(q, k, v):
-        return torch.nn.functional.scaled_dot_product_attention(q.transpose(0, 1), k.transpose(0, 1), v.transpose(0, 1)).transpose(0, 1)
-    odit.attention = attn32
-    try:
+    cfg = synth.VAE_CFG_22
+    sd = synth.make_vae_state_dict(cfg, seed=5)
+    z = torch.randn(48, 2, 16, 24, generator=torch.Generator().manual_seed(6))
+    with FlopCounterMode(display=False) as fc:
         t0 = time.time()
-        with torch.no_grad():
-            odit.block_forward(sd, "blocks.0.", x, e6, rope, ctx, c1, "wan23")
+        out = ovae.decode(sd, cfg, z)
         dt = time.time() - t0
-    finally:
-        odit.attention = orig
-    step_s = dt * cfg["num_layers"]
-    return {"value": 1.0 / step_s, "unit": "denoise-steps/sec", "cores": os.cpu_count(), "kind": "port",
+    assert torch.isfinite(out).all()
+    tf = fc.get_total_flops() / 1e12
+    return {"value": (tf / dt) / (485.04 / 8.0), "unit": "latents/s", "cores": os.cpu_count(), "kind": "port",
+            "sample": f"oracle decode of 2 latents 48x2x16x24 ({tf:.2f} TFLOP, {dt:.2f} s = {tf / dt:.2f} TFLOP/s fp32), "
+                      "scaled by FLOPs to the 704x1280 chunk (60.6 TFLOP per latent)"}
+
+
+def cpu_baseline(cfg, L, model):
+    """Reference restatement on the host cores: one full-width block at the full sequence length (oracle/fullsize.py), and the
+    same block on the same inputs through the device engine -> (cpu_baseline, parity)."""
+    from oracle import fullsize
+    torch.set_num_threads(os.cpu_count() or 1)
+    case = fullsize.make_block_case(cfg, "wan23", L, seed=0)
+    want, dt = fullsize.run_block_oracle(case)
+    base = {"value": 1.0 / (dt * cfg["num_layers"]), "unit": "denoise-steps/sec", "cores": os.cpu_count(), "kind": "port",
             "sample": f"1 of {cfg['num_layers']} DiT blocks at L={L} (fp32, {dt:.2f} s), extrapolated x{cfg['num_layers']}; embed/head excluded"}
+    # device leg: block 0 of the benchmarked model temporarily holds the case's weights
+    blk = model.blocks[0]
+    saved = {k: v.detach().clone() for k, v in blk.state_dict().items()}
+    blk.load_state_dict({k[len("blocks.0."):]: v for k, v in case["sd"].items()})
+    try:
+        rope_cs = torch.stack([case["rope"].real, case["rope"].imag], dim=-1).to(torch.float32)
+        dev = blk.modulation.device
+        got = model.engine.block_forward(0, case["x"].to(dev), case["e6"].to(dev), rope_cs.to(dev), case["ctx"].to(dev)).cpu()
+    finally:
+        blk.load_state_dict(saved)
+    par = fullsize.parity(got, want)
+    upd = fullsize.parity(got - case["x"], want - case["x"])
+    par.update(update_rel_l2=upd["rel_l2"], tolerance="rel_l2 <= 1e-2 (bf16 MFMA path vs fp32 reference restatement)",
+               what=f"one live 5B block at L={L}: device engine vs CPU oracle on identical inputs (weights in the model's dtype)")
+    return base, par
+
+
+def kernel_rooflines(prof, steps, ms_per_step, L, cfg, Lc=512):
+    """per kernel group: launches and average launch time from the HIP events recorded inside the timed steps, algorithmic work
+    per launch, achieved rate against the roofline that bounds it. Sorted by share of the step, largest first."""
+    C, Fd, H = cfg["dim"], cfg["ffn_dim"], cfg["num_heads"]
+    D = C // H
+    work = {   # group -> (bound, algorithmic flop or bytes per launch, description)
+        "attn_self": ("mfma", 4.0 * L * L * D * H, f"self-attention {L}x{L}x{H} heads, d={D}: attn_fwd_kernel_v7 (+ attn_combine_kernel for the "
+                      "query blocks of the partial last round, timed together as one yume_attn_fwd_ws call)"),
+        "attn_cross": ("mfma", 4.0 * L * Lc * D * H, f"cross-attention {L}x{Lc}x{H} heads: attn_fwd_kernel_v2"),
+        "gemm_qkv": ("mfma", 2.0 * L * 3 * C * C, f"QKV GEMM {L}x{3 * C}x{C}, transposed-V epilogue"),
+        "gemm_o": ("mfma", 2.0 * L * C * C, f"o-proj GEMM {L}x{C}x{C}, gate*y + residual epilogue"),
+        "gemm_cross_q": ("mfma", 2.0 * L * C * C, f"cross q GEMM {L}x{C}x{C}"),
+        "gemm_cross_o": ("mfma", 2.0 * L * C * C, f"cross o-proj GEMM {L}x{C}x{C}, residual epilogue"),
+        "gemm_ffn0": ("mfma", 2.0 * L * Fd * C, f"ffn.0 GEMM {L}x{Fd}x{C} + bias + GELU (gemm256_kernel + gemm128_kernel on the row remainder)"),
+        "gemm_ffn2": ("mfma", 2.0 * L * C * Fd, f"ffn.2 GEMM {L}x{C}x{Fd}, gate*y + residual epilogue"),
+        "adaln": ("hbm", 6.0 * L * C, "LayerNorm + modulate: 4*L*C read + 2*L*C written"),
+        "rmsnorm_rope": ("hbm", None, "RMSNorm (+RoPE) in place on q|k / cross q (2 B read + 2 B written per element)"),
+    }
+    out = []
+    for name, evs in prof.items():
+        if not evs:
+            continue
+        tot = sum(a.elapsed_time(b) for a, b in evs)
+        avg = tot / len(evs)
+        bound, w, desc = work.get(name, ("mfma", None, name))
+        r = {"group": name, "bound": bound, "kernel": desc, "launch_ms": avg, "launches_timed": len(evs),
+             "ms_per_step": tot / steps, "share_of_step": tot / steps / ms_per_step}
+        if w is not None and avg > 0:
+            if bound == "mfma":
+                ach = w / (avg * 1e-3) / 1e12
+                r.update(achieved=ach, peak=MFMA_BF16_PEAK_TFLOPS, unit="TFLOP/s", frac=ach / MFMA_BF16_PEAK_TFLOPS)
+            else:
+                ach = w / (avg * 1e-3) / 1e9
+                r.update(achieved=ach, peak=8000.0, unit="GB/s", frac=ach / 8000.0)
+        r["traffic"] = pmc_traffic_bytes(name)
+        out.append(r)
+    out.sort(key=lambda r: -r["ms_per_step"])
+    return out
+
+
+def _timed(fn, world):
+    """barrier + synchronize on both sides, max over ranks (the driver's contract)."""
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    r = fn()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+    return r, float(dt.item())
+
+
+def _build_5b(args, rank, dev):
+    from yume_amd import distributed as ydist
+    from yume_amd import synth
+    from yume_amd.wan23.modules.model import WanModel
+    cfg = dict(synth.CFG_5B)
+    if args.layers:
+        cfg["num_layers"] = args.layers
+    with torch.device(dev):
+        model = WanModel(**cfg)
+    if rank == 0:
+        synth.randomize_module_(model, seed=0)
+    model = model.to(torch.bfloat16).eval().requires_grad_(False)   # sample_5b.py:1241 casts the transformer to bf16
+    n_bcast = ydist.broadcast_module_(model, src=0)
+    return cfg, model, n_bcast
+
+
+def bench_tts(args, rank, world, dev):
+    """BASELINE configs[3]: Yume-5B-720P SDE/TTS sampling (fastvideo/sample/sample_tts.py:694-868: eta 0.3, time_travel_step 2,
+    interval 2 -> 74 model forwards per 50-step chunk), independent prompts sharded one per GPU (`index = (step-1)*world + rank`).
+    A step = one SAMPLER step of that loop (its forward, its look-ahead forwards and updates); the window [warmup, warmup+steps)
+    of the 50-step schedule is timed."""
+    from yume_amd import framepack, sampling, synth
+    cfg, model, n_bcast = _build_5b(args, rank, dev)
+    F, H, W, lfz, S, shift = 13, 44, 80, 8, 50, 7.0
+    plan = framepack.pack_plan(F, H, W, lfz)
+    g = torch.Generator(device=dev).manual_seed(3000 + rank)
+    hist = torch.randn((48, F - lfz, H, W), generator=g, device=dev)
+    latent = torch.cat([hist, torch.randn((48, lfz, H, W), generator=g, device=dev)], dim=1)
+    ctx = [torch.randn((77, 4096), generator=g, device=dev)]
+    sig = synth.sampling_sigmas(S, shift)
+    vel = sampling.make_velocity_5b(model, ctx, plan.seq_len, plan.n_hist_tok, plan.n_new_tok, sig, lfz)
+    histf = sampling.clean_history(hist)
+    w0, w1 = args.warmup, min(S, args.warmup + args.steps)
+    latent, cp = sampling.sde_tts_chunk(vel, latent, sig, lfz, histf, generator=g, i0=0, i1=w0, return_state=True)
+    (latent, cp), dt = _timed(lambda: sampling.sde_tts_chunk(vel, latent, sig, lfz, histf, generator=g, i0=w0, i1=w1, current_pred=cp,
+                                                             return_state=True), world)
+    assert torch.isfinite(latent).all()
+    nfw = sampling.tts_forward_count(S, i0=w0, i1=w1)
+    if rank == 0:
+        k = w1 - w0
+        print(json.dumps({"metric": "SDE/TTS sampler-steps/sec (Yume-5B 720P, 33-frame latent)", "value": world * k / dt, "unit": "sampler-steps/sec",
+                          "n_gpus": world, "steps": k, "warmup": w0, "ms_per_step": dt / k * 1e3, "higher_is_better": True, "scaling": "weak",
+                          "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+                          "config": {"workload": "Yume-5B-720P random-init, SDE (eta 0.3) + time-travel (step 2, interval 2) sampling of one "
+                                                 "33-frame 704x1280 chunk, L=9460, one prompt per GPU", "tokens": plan.seq_len,
+                                     "num_layers": cfg["num_layers"], "parallelism": f"dp{world} (independent prompts, replicated weights)"},
+                          "model_forwards_timed": nfw, "forwards_per_s": world * nfw / dt, "forwards_per_50_step_chunk": sampling.tts_forward_count(S),
+                          "ms_per_forward": dt / nfw * 1e3, "weight_broadcast_collectives": n_bcast}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def bench_longvideo(args, rank, world, dev):
+    """BASELINE configs[4]: the FramePack long-video loop of fastvideo/sample/sample_5b.py:920-1097 — VAE encode of the conditioning
+    clip, then `--chunks` (8) chunks of 2 s: `--steps` Euler steps each on [history | 8 noisy latents] (history grows by 8 latent
+    frames per chunk: L 9460 ... 12545), VAE decode of the 8 new latents after every chunk. Everything is inside the timed region
+    (the first chunk's encode included); one independent video per GPU. value = denoise steps of all ranks / time."""
+    from yume_amd import framepack, sampling, synth
+    from yume_amd.wan23.modules.vae2_2 import Wan2_2_VAE, WanVAE_
+    cfg, model, n_bcast = _build_5b(args, rank, dev)
+    H, W, lfz, shift = 44, 80, 8, 7.0
+    vcfg = synth.VAE_CFG_22
+    with torch.device(dev):
+        vm = WanVAE_(dim=vcfg["dim"], dec_dim=vcfg["dec_dim"], z_dim=vcfg["z_dim"], temperal_downsample=vcfg["temperal_downsample"])
+    vm.load_state_dict(synth.make_vae_state_dict(vcfg, seed=5, device=dev), strict=True)
+    vae = Wan2_2_VAE(device=dev, model=vm)
+    g = torch.Generator(device=dev).manual_seed(4000 + rank)
+    clip = torch.rand((3, 17, 704, 1280), generator=g, device=dev) * 2 - 1         # 17 frames -> 5 history latents
+    ctxs = [torch.randn((77, 4096), generator=g, device=dev) for _ in range(args.chunks)]
+    Ls, dec_ms = [], []
+
+    def run(n_chunks, steps):
+        hist = vae.encode([clip])[0]
+        for k in range(n_chunks):
+            plan = framepack.pack_plan(hist.shape[1] + lfz, H, W, lfz)
+            Ls.append(plan.seq_len)
+            hist, vids = sampling.long_video_5b(model, vae, hist, ctxs[k:k + 1], steps, shift, lfz, generator=g, decode=True)
+            assert torch.isfinite(vids[0]).all()
+        return hist
+    run(1, max(1, args.warmup))
+    Ls.clear()
+    hist, dt = _timed(lambda: run(args.chunks, args.steps), world)
+    if rank == 0:
+        nsteps = args.chunks * args.steps
+        print(json.dumps({"metric": "denoise-steps/sec (Yume-5B FramePack long video, VAE encode/decode per chunk in the timed region)",
+                          "value": world * nsteps / dt, "unit": "denoise-steps/sec", "n_gpus": world, "steps": nsteps, "warmup": args.warmup,
+                          "ms_per_step": dt / nsteps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
+                          "data": "synthetic",
+                          "config": {"workload": f"Yume-5B-720P random-init, {args.chunks} x 2 s chunks of 704x1280, {args.steps} Euler steps per chunk "
+                                                 "(the reference uses 50), 17-frame conditioning clip, Wan2.2 VAE encode + per-chunk decode",
+                                     "tokens_per_chunk": Ls, "num_layers": cfg["num_layers"], "parallelism": f"dp{world} (independent videos, replicated weights)"},
+                          "latents_per_s": world * args.chunks * lfz / dt, "final_history_latents": int(hist.shape[1]),
+                          "weight_broadcast_collectives": n_bcast}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
 
 
 def bench_14b(args, rank, world, dev):
@@ -199,8 +388,10 @@ def main():
     ap.add_argument("--sp", action="store_true",
                     help="5b only, not the headline: ONE chain split over the N ranks (Ulysses sequence parallelism, "
                          "SURVEY 8(f).2); value is that chain's steps/s, scaling 'strong'")
-    ap.add_argument("--workload", default="5b", choices=["5b", "14b"],
-                    help="5b = BASELINE configs[1] (the headline metric, default); 14b = configs[2] (Yume-I2V-14B-540P, 65-frame clip, CFG)")
+    ap.add_argument("--workload", default="5b", choices=["5b", "14b", "tts", "longvideo"],
+                    help="5b = BASELINE configs[1] (the headline metric, default); 14b = configs[2] (Yume-I2V-14B-540P, 65-frame clip, CFG); "
+                         "tts = configs[3] (SDE/TTS sampling, sampler steps); longvideo = configs[4] (FramePack chunks with VAE encode/decode)")
+    ap.add_argument("--chunks", type=int, default=8, help="longvideo only: number of 2 s chunks (BASELINE: 8)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -222,6 +413,10 @@ def main():
 
     if args.workload == "14b":
         return bench_14b(args, rank, world, dev)
+    if args.workload == "tts":
+        return bench_tts(args, rank, world, dev)
+    if args.workload == "longvideo":
+        return bench_longvideo(args, rank, world, dev)
     cfg = dict(synth.CFG_5B)
     if args.layers:
         cfg["num_layers"] = args.layers
@@ -257,7 +452,7 @@ def main():
 
     for i in range(args.warmup):
         latent = step(i, latent)
-    model.engine.prof = []
+    model.engine.prof = {}
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -299,10 +494,8 @@ def main():
     tmax = float(tmax.item())
 
     if rank == 0:
-        gemm_ms = sum(a.elapsed_time(b) for a, b in prof) / max(1, len(prof))
-        gemm_flop = 2.0 * L * cfg["ffn_dim"] * cfg["dim"]
-        achieved = gemm_flop / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
         ms_per_step = tmax / args.steps * 1e3
+        rl_all = kernel_rooflines(prof, args.steps, ms_per_step, L, cfg)
         out = {
             "metric": "denoise-steps/sec (Yume-5B 720P, 33-frame latent)",
             "value": (1 if sp else world) * args.steps / tmax, "unit": "denoise-steps/sec",
@@ -317,18 +510,20 @@ def main():
             "cached_context_ms_per_step": cached_ms,
             "model_tflop_per_step": flops_fwd_5b(L, n=cfg["num_layers"]) / 1e12,
             "model_tflops_per_gpu": flops_fwd_5b(L, n=cfg["num_layers"]) / 1e12 / (ms_per_step * 1e-3),
-            "roofline": {"bound": "mfma", "kernel": "ffn.0 GEMM 9460x14336x3072 + bias + GELU: gemm256_kernel<EPI_BF16_GELU, PlainA> on rows 0..9215 "
-                                                       "+ gemm128_kernel on the last 244 rows (one yume_gemm_bf16 call, timed as one launch)",
-                         "achieved": achieved, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / MFMA_BF16_PEAK_TFLOPS, "traffic": pmc_traffic_bytes(),
-                         "launch_ms": gemm_ms, "launches_timed": len(prof)},
+            "roofline": rl_all[0] if rl_all else None,          # the kernel group with the largest share of the step
+            "roofline_all": rl_all[1:],
         }
         if world == 1 and not args.no_cpu_baseline:
             try:
-                out["cpu_baseline"] = cpu_baseline(cfg, L, plan.n_hist_tok)
+                out["cpu_baseline"], out["parity"] = cpu_baseline(cfg, L, model)
             except Exception as e:  # noqa: BLE001 — a baseline failure must not hide the GPU number
                 out["cpu_baseline"] = {"value": None, "unit": "denoise-steps/sec", "cores": os.cpu_count(), "kind": "port",
                                        "sample": f"failed: {e}"}
+            if vae_res is not None:
+                try:
+                    vae_res["cpu_baseline"] = vae_cpu_baseline()
+                except Exception as e:  # noqa: BLE001
+                    vae_res["cpu_baseline"] = {"value": None, "unit": "latents/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e}"}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

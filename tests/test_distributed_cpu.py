@@ -54,6 +54,13 @@ def _worker(rank, world, port, n_prompts, out_dir):
     for (k, p), (_, q) in zip(net.state_dict().items(), ref.state_dict().items()):
         assert torch.equal(p, q), k
     assert n_coll >= 3                                  # fp32 split in >= 2 buckets + the bf16 bucket
+    # the scatter + all-gather distribution (every link of rank 0 carries a different slice) replicates the same bits
+    net2 = TinyNet(seed=200 + rank)
+    n2 = D.broadcast_module_(net2, src=1, bucket_bytes=64 * 1024, mode="scatter_allgather")
+    ref2 = TinyNet(seed=201)
+    for (k, p), (_, q) in zip(net2.state_dict().items(), ref2.state_dict().items()):
+        assert torch.equal(p, q), k
+    assert n2 == 2 * n_coll
     mine = D.shard_indices(n_prompts, rank, world)
     assert mine == [i for i in range(n_prompts) if i % world == rank]
     with torch.no_grad():

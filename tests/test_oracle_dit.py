@@ -76,3 +76,45 @@ def test_oracle_matches_live_reference(family, F, lfz, packed):
     got = run_oracle(fx, sd)
     assert got.shape == want.shape
     assert (got - want).abs().max().item() <= 2e-5
+
+
+def _cache_case():
+    from yume_amd import framepack
+    family, F, H, W, lfz = "wan", 13, 10, 12, 9
+    cfg = synth.tiny_cfg(family, layers=3)
+    sd = synth.make_dit_state_dict(cfg, family, seed=51)
+    a = synth.make_dit_inputs(cfg, family, F, H, W, n_text=9, seed=52)
+    b = synth.make_dit_inputs(cfg, family, F, H, W, n_text=9, seed=53)
+    L = framepack.pack_plan(F, H, W, lfz, F - 9).seq_len
+    return family, cfg, sd, a, b, L, lfz, [2, 0]
+
+
+def _oracle_cache_run(cfg, sd, a, b, L, lfz, cache_list):
+    out1, cache = odit.forward_wan(sd, cfg, a["x"], torch.tensor([700.0]), a["context"], L, a["clip_fea"][0], a["y"], 0.6, lfz,
+                                   cache_sample=True, return_cache=True, cache_list=cache_list)
+    out2, none = odit.forward_wan(sd, cfg, b["x"], torch.tensor([650.0]), b["context"], L, b["clip_fea"][0], b["y"], 0.6, lfz,
+                                  cache_sample=True, cache=cache, return_cache=False, cache_list=cache_list)
+    assert none is None
+    return out1, cache, out2
+
+
+def test_oracle_block_residual_cache_matches_golden():
+    """a13 (wan/modules/model.py:975-1000): fixture generated from the REAL reference by oracle/make_golden_cache.py."""
+    fx = load_golden("dit_wan_cache")
+    family, cfg, sd, a, b, L, lfz, cache_list = _cache_case()
+    out1, cache, out2 = _oracle_cache_run(cfg, sd, a, b, L, lfz, cache_list)
+    assert (out1 - fx["out_record"]).abs().max() <= 2e-5 and (out2 - fx["out_replay"]).abs().max() <= 2e-5
+    assert len(cache) == len(fx["cache"]) == 2
+    for c, r in zip(cache, fx["cache"]):
+        assert c.dtype == torch.bfloat16 and c.shape == r.shape and (c.float() - r.float()).abs().max() <= 2e-2 * r.float().abs().max()
+
+
+@pytest.mark.skipif(not ref_import.available(), reason="reference tree not present (GPU box)")
+def test_oracle_block_residual_cache_matches_live_reference():
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    from make_golden_cache import reference_cache_run
+    family, cfg, sd, a, b, L, lfz, cache_list = _cache_case()
+    r1, rc, r2 = reference_cache_run(cfg, sd, a, b, L, lfz, cache_list)
+    out1, cache, out2 = _oracle_cache_run(cfg, sd, a, b, L, lfz, cache_list)
+    assert (out1 - r1).abs().max() <= 2e-5 and (out2 - r2).abs().max() <= 2e-5
+    assert [tuple(c.shape) for c in cache] == [tuple(c.shape) for c in rc]

@@ -25,11 +25,20 @@ def flash_attention(q, k, v, q_lens=None, k_lens=None, dropout_p=0., softmax_sca
         raise NotImplementedError("yume_amd.flash_attention computes in bf16 (the reference default)")
     b, lq, n, d = q.shape
     lk = k.size(1)
-    if d != 128 or v.size(-1) != 128 or k.size(2) != n:
-        raise NotImplementedError("yume_amd.flash_attention: head_dim 128 and equal q/k head counts only")
+    if k.size(2) != n or v.size(-1) != d:
+        raise NotImplementedError("yume_amd.flash_attention: equal q/k/v head counts and head dims only")
+    if d > 128:
+        raise NotImplementedError(f"yume_amd.flash_attention: head_dim {d} > 128 is not built (the reference accepts <= 256; "
+                                  "no Yume model uses it)")
+    d_in = d
+    if d < 128:
+        # zero columns add nothing to q.k and produce zero output columns: exact. (CLIP ViT-H/14 has head_dim 80.)
+        pad = lambda t: torch.nn.functional.pad(t, (0, 128 - d_in))
+        q, k, v = pad(q), pad(k), pad(v)
+        d = 128
     out_dtype = q.dtype
     out = torch.empty((b, lq, n * d), dtype=torch.bfloat16, device=q.device)
-    scale = softmax_scale if softmax_scale is not None else 1.0 / math.sqrt(d)
+    scale = softmax_scale if softmax_scale is not None else 1.0 / math.sqrt(d_in)
     for i in range(b):
         nq = int(q_lens[i]) if q_lens is not None else lq
         nk = int(k_lens[i]) if k_lens is not None else lk
@@ -46,7 +55,7 @@ def flash_attention(q, k, v, q_lens=None, k_lens=None, dropout_p=0., softmax_sca
         ops.attn_fwd(qi, ki, vt, out[i, :nq], nq, nk, n, scale=scale)
         if nq < lq:
             out[i, nq:].zero_()   # flash-attn's varlen packing leaves padded queries out; the reference never reads them
-    return out.view(b, lq, n, d).type(out_dtype)
+    return out.view(b, lq, n, d)[..., :d_in].type(out_dtype)
 
 
 def attention(q, k, v, q_lens=None, k_lens=None, dropout_p=0., softmax_scale=None, q_scale=None, causal=False,

@@ -4,8 +4,10 @@ The reference's only multi-GPU mode at inference is data parallel over samples â
 (fastvideo/sample/sample_5b.py:782-785) â€” with the DiT wrapped in FSDP FULL_SHARD, i.e. a parameter all-gather per block
 per forward that exists only because of 80 GB GPUs. On MI355X (288 GB HBM3E) the weights are replicated, so there is NO
 collective inside the step loop; RCCL (torch.distributed backend "nccl" on ROCm; "gloo" in the CPU tests) is used for
-  * broadcast_module_: one-time weight broadcast from rank 0 in few, large flat buckets (xGMI rings are per-link bound,
-    so bucket size rather than message count is what matters);
+  * broadcast_module_: one-time weight replication from rank 0 in few, large flat buckets (xGMI rings are per-link bound,
+    so bucket size rather than message count is what matters); mode "scatter_allgather" (SURVEY Â§5 / Â§8(e)) sends each peer
+    a DIFFERENT 1/world slice of the bucket â€” rank 0's seven xGMI links each carry 1/8 of the bytes instead of one ring
+    carrying all of them â€” and completes the replicas with one all-gather in which every link of every GPU works;
   * all_gather_results / gather_scalars: result latents, checksums and timings at chunk end.
 """
 import os
@@ -37,10 +39,16 @@ def shard_indices(n_items, rank, world):
 
 
 @torch.no_grad()
-def broadcast_module_(module, src=0, bucket_bytes=1 << 30):
-    """Replicate rank `src`'s parameters and buffers on every rank with flat-bucketed broadcasts."""
+def broadcast_module_(module, src=0, bucket_bytes=1 << 30, mode=None):
+    """Replicate rank `src`'s parameters and buffers on every rank in flat buckets. mode "broadcast" = one dist.broadcast per
+    bucket; "scatter_allgather" = dist.scatter of world slices + dist.all_gather_into_tensor (2 collectives per bucket; the
+    bucket is padded to a multiple of world). Default: YUME_WEIGHT_DIST env var, else "broadcast". Returns the collective count."""
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return 0
+    mode = mode or os.environ.get("YUME_WEIGHT_DIST", "broadcast")
+    if mode not in ("broadcast", "scatter_allgather"):
+        raise ValueError(f"unknown weight distribution mode {mode!r}")
+    world, rank = dist.get_world_size(), dist.get_rank()
     tensors = [p.data for p in module.parameters()] + [b.data for b in module.buffers()]
     n_coll = 0
     by_dtype = {}
@@ -55,14 +63,22 @@ def broadcast_module_(module, src=0, bucket_bytes=1 << 30):
                 group.append(ts[i])
                 n += ts[i].numel()
                 i += 1
-            flat = torch.empty(n, dtype=dtype, device=dev)
+            npad = (n + world - 1) // world * world if mode == "scatter_allgather" else n
+            flat = torch.empty(npad, dtype=dtype, device=dev)
             off = 0
-            if dist.get_rank() == src:
+            if rank == src:
                 for t in group:
                     flat[off:off + t.numel()].copy_(t.reshape(-1))
                     off += t.numel()
-            dist.broadcast(flat, src=src)
-            n_coll += 1
+                flat[n:].zero_()
+            if mode == "broadcast":
+                dist.broadcast(flat, src=src)
+                n_coll += 1
+            else:
+                piece = torch.empty(npad // world, dtype=dtype, device=dev)
+                dist.scatter(piece, list(flat.view(world, -1).unbind(0)) if rank == src else None, src=src)
+                dist.all_gather_into_tensor(flat, piece)
+                n_coll += 2
             off = 0
             for t in group:
                 t.copy_(flat[off:off + t.numel()].view_as(t))

@@ -36,7 +36,7 @@ class DiTEngine:
         self._packed_key = None
         self._ws = {}
         self._plan_cache = {}
-        self.prof = None   # list collecting (start, end) HIP event pairs of the ffn.0 GEMM when profiling
+        self.prof = None   # dict kernel-group -> list of (start, end) HIP event pairs when bench.py profiles the timed steps
         # the text / CLIP embeddings and every block's cross-attention K, V^T depend only on the
         # conditioning, not on the latent or the timestep; with cache_context they are computed once per conditioning
         # tensor (same object, same version) instead of once per denoise step. Off by default = the reference's work.
@@ -50,8 +50,23 @@ class DiTEngine:
         self._ctx_key = None
         self._ctx_refs = None
 
+    # ------------------------------------------------------------------ profiling (bench.py)
+    def _timed(self, name, fn, *a, **k):
+        """run one kernel call; with self.prof set, bracket it with HIP events recorded on the launch stream (torch's current
+        stream IS the stream ops.* enqueue on)."""
+        if self.prof is None:
+            return fn(*a, **k)
+        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        ev[0].record()
+        r = fn(*a, **k)
+        ev[1].record()
+        self.prof.setdefault(name, []).append(ev)
+        return r
+
     # ------------------------------------------------------------------ weights
     def _param_key(self):
+        # walked once per forward: (storage address, in-place version, dtype) of every parameter — a load_state_dict, an
+        # optimizer step or a .to(dtype) re-packs; cheap next to one forward (≈1 k tensors), and cached per forward call
         return tuple((p.data_ptr(), p._version, p.dtype) for p in self.model.parameters())
 
     def _pack(self):
@@ -239,9 +254,12 @@ class DiTEngine:
             ops.rmsnorm_rows_periodic(kc.view(nk * nb, C), C, nk_w, self.model.eps)
         return kc, vct
 
-    def _blocks(self, xs, L, tab, row_idx, R, rope, n_rope, ctx, n_img, ctx_fresh=True, n_keys=None):
+    def _blocks(self, xs, L, tab, row_idx, R, rope, n_rope, ctx, n_img, ctx_fresh=True, n_keys=None, only=None, cache=None):
         """xs fp32 [L, C] in/out. tab fp32 [nb, R, 6, C]; rope fp32 [n_rope, 64, 2] (n_rope == L here).
-        With sequence parallelism L is this rank's (padded) chunk and n_keys the true global token count."""
+        With sequence parallelism L is this rank's (padded) chunk and n_keys the true global token count.
+        only: run just these block indices (tab[j] then belongs to only[j]) — the WanAttentionBlock.forward seam.
+        cache: (mode, cache_list, tensors) block-residual cache of wan/modules/model.py:985-1000: mode 'record' appends
+        bf16 (x_out - x_in) of the listed blocks, 'replay' adds the stored residual instead of running them."""
         m = self.model
         C, H, Fd, eps = m.dim, m.num_heads, m.ffn_dim, m.eps
         Lp = _round_up(L, 8)
@@ -255,48 +273,82 @@ class DiTEngine:
         kc_t, vct_t = self._cross_kv("t", ctx[n_img:], ntxt, self.P["wkv_c"], self.P["bkv_c"], self.P["nk_c"], ctx_fresh)
         if n_img:
             kc_i, vct_i = self._cross_kv("i", ctx[:n_img], n_img, self.P["wkv_i"], self.P["bkv_i"], self.P["nk_i"], ctx_fresh)
-        for i, d in enumerate(self.P["blocks"]):
-            tb = tab[i]                      # [R, 6, C]
+        T = self._timed
+        ids = range(len(self.P["blocks"])) if only is None else only
+        for j, i in enumerate(ids):
+            d = self.P["blocks"][i]
+            if cache is not None and i in cache[1]:
+                if cache[0] == "replay":
+                    # reference: `x = x + cache[cache_list.index(cnt_blocks - 1)]` (fp32 + bf16), the block is not run
+                    xs.add_(cache[2][cache[1].index(i)].reshape(L, C).to(torch.float32))
+                    continue
+                x_in = xs.clone()
+            tb = tab[j if only is not None else i]                      # [R, 6, C]
             shift_sa, scale_sa, gate_sa = tb[:, 0], tb[:, 1], tb[:, 2]
             shift_ff, scale_ff, gate_ff = tb[:, 3], tb[:, 4], tb[:, 5]
             # --- self attention
-            ops.adaln_modulate(xs, scale_sa, shift_sa, ts, row_idx, True, h, 0, eps)
-            ops.gemm_bf16(h, d["wqkv"], d["bqkv"], qk, EPI_BF16_SPLITT, out_t=vt, n_split=2 * C, variant=self.gemm_variant)
+            T("adaln", ops.adaln_modulate, xs, scale_sa, shift_sa, ts, row_idx, True, h, 0, eps)
+            T("gemm_qkv", ops.gemm_bf16, h, d["wqkv"], d["bqkv"], qk, EPI_BF16_SPLITT, out_t=vt, n_split=2 * C, variant=self.gemm_variant)
             if n_rope == L:
-                ops.rmsnorm_rope(qk, C, 2, d["nqk"], eps, rope)
+                T("rmsnorm_rope", ops.rmsnorm_rope, qk, C, 2, d["nqk"], eps, rope)
+            elif n_rope == 0:
+                ops.rmsnorm_rope(qk, C, 2, d["nqk"], eps, None)
             else:
                 ops.rmsnorm_rope(qk[:n_rope], C, 2, d["nqk"], eps, rope)
                 ops.rmsnorm_rope(qk[n_rope:], C, 2, d["nqk"], eps, None)
             if self.sp is None:
-                ops.attn_fwd(qk[:, :C], qk[:, C:], vt, att, L, L, H, variant=self.attn_variant)
+                T("attn_self", ops.attn_fwd, qk[:, :C], qk[:, C:], vt, att, L, n_keys if n_keys is not None else L, H, variant=self.attn_variant)
                 sa = att
             else:      # Ulysses: all tokens x this rank's heads, then back (2 collectives, yume_amd/ulysses.py)
                 qf, kf, vtf = self.sp.exchange_qkv(qk, vt, C)
                 of = self._buf("att_sp", (qf.shape[0], qf.shape[1]), torch.bfloat16)
                 ops.attn_fwd(qf, kf, vtf, of, qf.shape[0], n_keys, H // self.sp.world, variant=self.attn_variant)
                 sa = self.sp.exchange_out(of)
-            ops.gemm_bf16(sa, d["wo"], d["bo"], xs, EPI_RESID, gate=gate_sa, gate_stride=ts, row_idx=row_idx, variant=self.gemm_variant)
+            T("gemm_o", ops.gemm_bf16, sa, d["wo"], d["bo"], xs, EPI_RESID, gate=gate_sa, gate_stride=ts, row_idx=row_idx, variant=self.gemm_variant)
             # --- cross attention
             if "n3w" in d:
-                ops.adaln_modulate(xs, d["n3w"], d["n3b"], 0, None, False, h, 0, eps)
+                T("adaln", ops.adaln_modulate, xs, d["n3w"], d["n3b"], 0, None, False, h, 0, eps)
             else:
                 ops.cast_bf16(xs, L, h)
-            ops.gemm_bf16(h, d["wq_c"], d["bq_c"], qk[:, :C], EPI_BF16, variant=self.gemm_variant)
-            ops.rmsnorm_rope(qk[:, :C], C, 1, d["nq_c"], eps)
-            ops.attn_fwd(qk[:, :C], kc_t[:, i * C:(i + 1) * C], vct_t[i * C:(i + 1) * C], att, L, ntxt, H, variant=self.attn_variant)
+            T("gemm_cross_q", ops.gemm_bf16, h, d["wq_c"], d["bq_c"], qk[:, :C], EPI_BF16, variant=self.gemm_variant)
+            T("rmsnorm_rope", ops.rmsnorm_rope, qk[:, :C], C, 1, d["nq_c"], eps)
+            T("attn_cross", ops.attn_fwd, qk[:, :C], kc_t[:, i * C:(i + 1) * C], vct_t[i * C:(i + 1) * C], att, L, ntxt, H, variant=self.attn_variant)
             if n_img:
-                ops.attn_fwd(qk[:, :C], kc_i[:, i * C:(i + 1) * C], vct_i[i * C:(i + 1) * C], att, L, n_img, H, accumulate=True, variant=self.attn_variant)
-            ops.gemm_bf16(att, d["wo_c"], d["bo_c"], xs, EPI_RESID, variant=self.gemm_variant)
+                T("attn_cross", ops.attn_fwd, qk[:, :C], kc_i[:, i * C:(i + 1) * C], vct_i[i * C:(i + 1) * C], att, L, n_img, H, accumulate=True, variant=self.attn_variant)
+            T("gemm_cross_o", ops.gemm_bf16, att, d["wo_c"], d["bo_c"], xs, EPI_RESID, variant=self.gemm_variant)
             # --- FFN
-            ops.adaln_modulate(xs, scale_ff, shift_ff, ts, row_idx, True, h, 0, eps)
-            if self.prof is not None:     # bench.py: HIP events around the dominant kernel, same stream
-                ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-                ev[0].record()
-            ops.gemm_bf16(h, d["w1"], d["b1"], ff, EPI_BF16_GELU, variant=self.gemm_variant)
-            if self.prof is not None:
-                ev[1].record()
-                self.prof.append(ev)
-            ops.gemm_bf16(ff, d["w2"], d["b2"], xs, EPI_RESID, gate=gate_ff, gate_stride=ts, row_idx=row_idx, variant=self.gemm_variant)
+            T("adaln", ops.adaln_modulate, xs, scale_ff, shift_ff, ts, row_idx, True, h, 0, eps)
+            T("gemm_ffn0", ops.gemm_bf16, h, d["w1"], d["b1"], ff, EPI_BF16_GELU, variant=self.gemm_variant)
+            T("gemm_ffn2", ops.gemm_bf16, ff, d["w2"], d["b2"], xs, EPI_RESID, gate=gate_ff, gate_stride=ts, row_idx=row_idx, variant=self.gemm_variant)
+            if cache is not None and cache[0] == "record" and i in cache[1]:
+                cache[2].append((xs - x_in).to(torch.bfloat16).unsqueeze(0))     # reference keeps [B, L, C] bf16
+
+    # ------------------------------------------------------------------ one block through the engine (operator seam)
+    @torch.no_grad()
+    def block_forward(self, i, x, e, rope_cs, context, n_img=0):
+        """WanAttentionBlock.forward for block i (reference wan23/modules/model.py:272-316, wan/modules/model.py:444-493):
+        x [L, C] float; e fp32 [L, 6, C] (per token, 5B) or [1|6, C] (one row, 14B) — the time projection BEFORE the
+        block's own modulation is added; rope_cs fp32 [n_rope, 64, 2] (cos, sin) of the first n_rope tokens or None;
+        context [Lc, C] already embedded (the first n_img rows are CLIP image tokens). Returns fp32 [L, C]."""
+        self.ensure_packed()
+        C = self.model.dim
+        L = x.shape[0]
+        xs = self._buf("xs_blk", (L, C), torch.float32)
+        xs.copy_(x.to(device=self.dev, dtype=torch.float32))
+        e2 = e.to(device=self.dev, dtype=torch.float32).reshape(-1, 6 * C).contiguous()
+        R = e2.shape[0]
+        if R not in (1, L):
+            raise RuntimeError(f"block modulation e has {R} rows for {L} tokens (expected 1 or one per token)")
+        tab = self._buf("tab_blk", (1, R, 6 * C), torch.float32)
+        ops.modulation_table(self.P["mod_all"][i:i + 1].contiguous(), e2, tab)
+        row_idx = torch.arange(L, dtype=torch.int32, device=self.dev) if R > 1 else None
+        ctx = context.to(device=self.dev, dtype=torch.bfloat16).contiguous()
+        n_rope = 0 if rope_cs is None else rope_cs.shape[0]
+        if n_rope == 0:
+            rope_cs = torch.zeros((1, 64, 2), dtype=torch.float32, device=self.dev)
+        self._ctx_key = None                                     # the per-conditioning cache belongs to forward_one
+        self._blocks(xs, L, tab.view(1, R, 6, C), row_idx, R, rope_cs.to(self.dev).contiguous(), n_rope, ctx, n_img, True, only=[i])
+        return xs.clone()
 
     def _head(self, xs_new, row_idx_new, e, R, grid):
         """xs_new fp32 [Ln, C] -> fp32 [Cout, F, 2*Hp, 2*Wp]."""
@@ -325,7 +377,7 @@ class DiTEngine:
 
     # ------------------------------------------------------------------ one sample forward
     @torch.no_grad()
-    def forward_one(self, u, t, context, clip_fea=None, packed=True, lfz=8, n_sel=None):
+    def forward_one(self, u, t, context, clip_fea=None, packed=True, lfz=8, n_sel=None, cache=None):
         """u [Cin, F, H, W] (fp32|bf16, x and y already concatenated); t tensor; context [Ltxt, text_dim].
         Returns fp32 [Cout, F', H, W]."""
         self.ensure_packed()
@@ -354,7 +406,11 @@ class DiTEngine:
             groups, grid = plan.groups, plan.new_grid
         else:
             def build():
-                hp, wp = -(-H // 2), -(-W // 2)
+                if H % 2 or W % 2:
+                    # the base patch_embedding is an UNPADDED stride-2 Conv3d (model.py:455): odd sizes lose their last row / column
+                    # there, while the pyramid levels pad (convpadd); no shipped resolution is odd — refuse instead of guessing
+                    raise RuntimeError(f"latent H x W = {H} x {W} must be even for the (1, 2, 2) patch embedding")
+                hp, wp = H // 2, W // 2
                 rope = framepack.rope_cos_sin([(0, F, hp, wp)], D).to(self.dev)
                 return framepack.Group(0, F, 0, hp, wp), rope
             g0, rope = self._clip_tables(("u", F, H, W), build)
@@ -416,8 +472,10 @@ class DiTEngine:
             self._text_ctx(context, ctx[n_img:])
 
         if self.sp is not None:
+            if cache is not None:
+                raise NotImplementedError("cache_sample is not combined with sequence parallelism")
             return self._forward_sp(xs, L, n_hist, tab.view(nb, R, 6, C), row_idx, R, rope, ctx, n_img, ctx_fresh, e, grid)
-        self._blocks(xs, L, tab.view(nb, R, 6, C), row_idx, R, rope, L, ctx, n_img, ctx_fresh)
+        self._blocks(xs, L, tab.view(nb, R, 6, C), row_idx, R, rope, L, ctx, n_img, ctx_fresh, cache=cache)
         ridx_new = row_idx[n_hist:] if row_idx is not None else None
         return self._head(xs[n_hist:], ridx_new, e, R, grid)
 

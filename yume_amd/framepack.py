@@ -40,6 +40,11 @@ class Group:
 
 
 def _grid(h, w, level):
+    """token grid of a level. Level 0 is the reference's UNPADDED stride-2 patch_embedding (wan23/modules/model.py:455): it
+    floors, so odd sizes would silently lose a row / column there while the pyramid levels zero-pad (convpadd, :588-741);
+    every shipped resolution is even and an odd one is refused rather than guessed."""
+    if level == 0 and (h % 2 or w % 2):
+        raise ValueError(f"latent H x W = {h} x {w} must be even for the (1, 2, 2) patch embedding")
     if level == 5:
         h, w = -(-h // 4), -(-w // 4)
         level = 4

@@ -81,11 +81,13 @@ def _sde_step(x, v, s, s_next, eta, last_is_50, gen):
 
 @torch.no_grad()
 def sde_tts_chunk(velocity: Callable, latent, sigmas: List[float], lfz: int, history: Callable, sde=True, eta=0.3,
-                  travel_step=2, travel_interval=2, generator: Optional[torch.Generator] = None):
-    """sample_tts.py:694-868. `velocity(latent, i)` is evaluated at sigma index i; returns the final latent."""
+                  travel_step=2, travel_interval=2, generator: Optional[torch.Generator] = None, i0=0, i1=None, current_pred=None,
+                  return_state=False):
+    """sample_tts.py:694-868. `velocity(latent, i)` is evaluated at sigma index i; returns the final latent.
+    i0 / i1 / current_pred / return_state run the sampler steps [i0, i1) only and hand the look-ahead state on (bench.py times a
+    window of steps of the 50-step loop); the defaults run the whole chunk."""
     S = len(sigmas)
-    current_pred = None
-    for i in range(S):
+    for i in range(i0, S if i1 is None else min(i1, S)):
         v = velocity(latent, i)
         x = latent[:, -lfz:]
         nxt = sigmas[i + 1] if i + 1 < S else 0.0
@@ -112,14 +114,16 @@ def sde_tts_chunk(velocity: Callable, latent, sigmas: List[float], lfz: int, his
             # step i is REDONE with the look-ahead velocity (stale from the last travelled step when the range was empty)
             temp = x + (nxt - sigmas[i]) * current_pred[:, -lfz:]
         latent = torch.cat([history(min(S - 1, i + 1)), temp], dim=1)
-    return latent
+    return (latent, current_pred) if return_state else latent
 
 
-def tts_forward_count(S, travel_step=2, travel_interval=2):
-    """number of velocity evaluations of sde_tts_chunk (S=50 -> 74)."""
-    n = S
-    for i in range(0, S, travel_interval):
-        n += max(0, min(S - 1, i + travel_step) - (i + 1))
+def tts_forward_count(S, travel_step=2, travel_interval=2, i0=0, i1=None):
+    """number of velocity evaluations of sde_tts_chunk over the sampler steps [i0, i1) (S=50 -> 74)."""
+    i1 = S if i1 is None else min(i1, S)
+    n = i1 - i0
+    for i in range(i0, i1):
+        if travel_interval > 0 and i % travel_interval == 0:
+            n += max(0, min(S - 1, i + travel_step) - (i + 1))
     return n
 
 

@@ -237,6 +237,21 @@ def umt5_xxl(encoder_only=True, return_tokenizer=False, dtype=torch.float32, dev
     return model.to(dtype=dtype, device=device)
 
 
+def clean_prompt(text):
+    """the `clean='whitespace'` preprocessing of the reference tokenizer wrapper (wan/modules/tokenizers.py:12-22,75-77):
+    ftfy.fix_text, html.unescape twice, strip, runs of whitespace -> one blank. ftfy is required exactly as in the reference:
+    without it mojibake would silently tokenise differently, so its absence is an error, not a fallback."""
+    import html
+    import re
+    try:
+        import ftfy
+    except ImportError as e:  # pragma: no cover - depends on the environment
+        raise RuntimeError("prompt cleaning needs the `ftfy` package (the reference's tokenizer wrapper calls ftfy.fix_text); "
+                           "install it or pass pre-tokenised ids to encode_ids()") from e
+    text = html.unescape(html.unescape(ftfy.fix_text(text))).strip()
+    return re.sub(r"\s+", " ", text).strip()
+
+
 class T5EncoderModel:
     """reference t5.py:470-513. The tokenizer (HuggingFace `google/umt5-xxl`, reference tokenizers.py) is host-side glue and is
     only built when `tokenizer_path` points at local tokenizer files; `encode_ids(ids, mask)` takes pre-tokenised input."""
@@ -266,6 +281,7 @@ class T5EncoderModel:
             raise RuntimeError("T5EncoderModel was built without tokenizer files; use encode_ids(ids, mask)")
         if isinstance(texts, str):
             texts = [texts]
+        texts = [clean_prompt(t) for t in texts]            # HuggingfaceTokenizer(clean='whitespace'), t5.py:499-500
         enc = self.tokenizer(texts, return_tensors="pt", padding="max_length", truncation=True, max_length=self.text_len,
                              add_special_tokens=True)
         return self.encode_ids(enc.input_ids, enc.attention_mask)

@@ -4,12 +4,13 @@ Same contract as yume_amd/wan23/modules/model.py; differences follow the referen
 wan/modules/model.py: the model is always 'i2v' (:609-610), x and y are concatenated on channels (:765-766),
 one scalar timestep per sample (:923-928), CLIP image tokens go through img_emb and a second cross-attention
 with k_img/v_img whose output is summed before the o projection (:348-389, :939-941), the FramePack branch is
-chosen by `rand_num_img >= 0.4` and by a hard-coded `f_num - 9` (:768,781), and forward returns (tensor, cache).
+chosen by `rand_num_img >= 0.4` and by a hard-coded `f_num - 9` (:768,781), and forward returns (tensor, cache) with the
+block-residual cache of :985-1000 (cache_sample / cache / return_cache / cache_list) implemented as in the reference.
 """
 import torch
 import torch.nn as nn
 
-from ...wan23.modules.model import Head, WanAttentionBlock, WanModel as _Base, _pyramid_conv
+from ...wan23.modules.model import Head, WanAttentionBlock as _Block23, WanModel as _Base, _pyramid_conv
 
 __all__ = ["WanModel"]
 
@@ -21,6 +22,24 @@ class MLPProj(nn.Module):
         super().__init__()
         self.proj = nn.Sequential(nn.LayerNorm(in_dim), nn.Linear(in_dim, in_dim), nn.GELU(),
                                   nn.Linear(in_dim, out_dim), nn.LayerNorm(out_dim))
+
+
+class WanAttentionBlock(_Block23):
+    """14B block: the reference signature has `cross_attn_type` first and per-sample e [B, 6, C]
+    (wan/modules/model.py:398-493); the first 257 context tokens are the CLIP image tokens (WanI2VCrossAttention, :362-366)."""
+
+    def __init__(self, cross_attn_type, dim, ffn_dim, num_heads, window_size=(-1, -1), qk_norm=True, cross_attn_norm=False, eps=1e-6):
+        super().__init__(dim, ffn_dim, num_heads, window_size, qk_norm, cross_attn_norm, eps, with_img=True)
+        self.cross_attn_type = cross_attn_type
+
+    def forward(self, x, e, seq_lens, grid_sizes, freqs, context, context_lens, rand_num_img=None, ids_keep=None,
+                ids_restore=None, mask_token=None, seq_lens1=None, cnt_blocks=None):
+        packed = rand_num_img is not None and rand_num_img >= 0.4      # rope_apply's per-token branch (:86-100)
+        return super().forward(x, e.unsqueeze(1) if e.dim() == 3 else e, seq_lens, grid_sizes, freqs, context, context_lens,
+                               ids_keep, ids_restore, mask_token, flag=packed)
+
+    def _n_img(self, ctx_rows):
+        return 257
 
 
 class WanModel(_Base):
@@ -47,9 +66,10 @@ class WanModel(_Base):
         self.time_embedding = nn.Sequential(nn.Linear(freq_dim, dim), nn.SiLU(), nn.Linear(dim, dim))
         self.time_projection = nn.Sequential(nn.SiLU(), nn.Linear(dim, dim * 6))
         self.blocks = nn.ModuleList([
-            WanAttentionBlock(dim, ffn_dim, num_heads, window_size, qk_norm, cross_attn_norm, eps, with_img=True)
+            WanAttentionBlock("i2v_cross_attn", dim, ffn_dim, num_heads, window_size, qk_norm, cross_attn_norm, eps)
             for _ in range(num_layers)])
         self.head = Head(dim, out_dim, patch_size, eps)
+        self._bind_blocks()
         self.img_emb = MLPProj(1280, dim)
         self.init_weights()
         self._engine = None
@@ -70,12 +90,16 @@ class WanModel(_Base):
         assert clip_fea is not None and y is not None
         if enable_mask:
             raise NotImplementedError("enable_mask (MDT token masking) is a training-time path")
+        # block-residual cache (:985-1000): `return_cache` records bf16 (x_out - x_in) of the blocks in cache_list (in block
+        # order), a later call with the same cache_list adds `cache[cache_list.index(block)]` instead of running the block
+        blk_cache = None
         if cache_sample:
-            raise NotImplementedError("cache_sample (block-residual replay) is never enabled by the Yume samplers; "
-                                      "it is not part of the fused path")
+            if cache is None:
+                cache = []
+            blk_cache = ("record" if return_cache else "replay", list(cache_list), cache)
         u = torch.cat([x[0], y[0]], dim=0)
         packed = rand_num_img is not None and rand_num_img >= 0.4
         out = self.engine.forward_one(u, t.reshape(-1)[:1], context[0], clip_fea=clip_fea[0] if clip_fea.dim() == 3
                                       else clip_fea, packed=packed, lfz=latent_frame_zero,
-                                      n_sel=(u.shape[1] - 9) if packed else None)
-        return out, None
+                                      n_sel=(u.shape[1] - 9) if packed else None, cache=blk_cache)
+        return out, (cache if cache_sample and return_cache else None)

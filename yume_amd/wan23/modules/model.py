@@ -7,7 +7,10 @@ signature (reference: wan23/modules/model.py:369-495,547-865) so `fastvideo/samp
 only OWN parameters; the arithmetic runs in hand-written HIP kernels through yume_amd.dit.DiTEngine.
 There is no PyTorch fallback: on a machine without the built extension the forward raises.
 """
+import json
 import math
+import os
+import weakref
 
 import torch
 import torch.nn as nn
@@ -66,8 +69,54 @@ class WanAttentionBlock(nn.Module):
         self.ffn = nn.Sequential(nn.Linear(dim, ffn_dim), nn.GELU(approximate="tanh"), nn.Linear(ffn_dim, dim))
         self.modulation = nn.Parameter(torch.randn(1, 6, dim) / dim ** 0.5)
 
-    def forward(self, *a, **k):
-        raise RuntimeError("WanAttentionBlock is executed by the fused HIP engine via WanModel.forward")
+    # set by the owning WanModel (weak reference: the block is a registered submodule of it)
+    _owner = None
+    _index = -1
+
+    def _bind(self, model, index):
+        object.__setattr__(self, "_owner", weakref.ref(model))
+        object.__setattr__(self, "_index", index)
+
+    @staticmethod
+    def _rope_rows(freqs, grid, n_tokens, flag):
+        """(cos, sin) rows [n, 64, 2] fp32 for the tokens that get RoPE. flag=True (FramePack): `freqs` is the per-token complex
+        table [L, 1, 64] (rope_apply, model.py:95-104); else the [1024, 64] axis table indexed by the (f, h, w) grid (:52-70)."""
+        if flag:
+            fr = freqs.reshape(-1, freqs.shape[-1])[:n_tokens]
+        else:
+            f, h, w = (int(v) for v in grid)
+            c = freqs.shape[-1]
+            a, b, d = freqs.reshape(-1, c).split([c - 2 * (c // 3), c // 3, c // 3], dim=1)
+            fr = torch.cat([a[:f].view(f, 1, 1, -1).expand(f, h, w, -1), b[:h].view(1, h, 1, -1).expand(f, h, w, -1),
+                            d[:w].view(1, 1, w, -1).expand(f, h, w, -1)], dim=-1).reshape(f * h * w, -1)
+        return torch.stack([fr.real, fr.imag], dim=-1).to(torch.float32)
+
+    def forward(self, x, e, seq_lens, grid_sizes, freqs, context, context_lens, ids_keep=None, ids_restore=None,
+                mask_token=None, flag=True):
+        """One block through the HIP engine with the reference's arguments (model.py:272-316): x [B, L, C]; e fp32
+        [B, L1, 6, C] (the time projection, before this block's modulation is added); freqs as `flag` says (see
+        _rope_rows); context [B, Lc, C] already embedded. Tokens at positions >= seq_lens[b] are padding: the reference
+        attends only the first seq_lens[b] keys and never reads those rows back; they are returned unchanged here."""
+        if ids_keep is not None or ids_restore is not None:
+            raise NotImplementedError("ids_keep / ids_restore (MDT token masking) is a training-time path")
+        owner = self._owner() if self._owner is not None else None
+        if owner is None:
+            raise RuntimeError("WanAttentionBlock.forward needs the WanModel that owns the block (it runs on that model's engine)")
+        assert e.dtype == torch.float32
+        outs = []
+        for b in range(x.shape[0]):
+            n = int(seq_lens[b]) if seq_lens is not None else x.shape[1]
+            rope = self._rope_rows(freqs, None if flag else grid_sizes[b], n, flag)
+            nc = int(context_lens[b]) if context_lens is not None else context.shape[1]
+            eb = e[b]
+            if eb.dim() == 3 and eb.shape[0] not in (1, n):
+                eb = eb[:n]
+            y = owner.engine.block_forward(self._index, x[b, :n], eb, rope[:n], context[b, :nc], n_img=self._n_img(context[b, :nc]))
+            outs.append(torch.cat([y.to(x.dtype), x[b, n:]], dim=0) if n < x.shape[1] else y.to(x.dtype))
+        return torch.stack(outs)
+
+    def _n_img(self, ctx_rows):
+        return 0
 
 
 class Head(nn.Module):
@@ -119,6 +168,7 @@ class WanModel(nn.Module):
             WanAttentionBlock(dim, ffn_dim, num_heads, window_size, qk_norm, cross_attn_norm, eps)
             for _ in range(num_layers)])
         self.head = Head(dim, out_dim, patch_size, eps)
+        self._bind_blocks()
         self.init_weights()
         # pyramid patch embeddings are created in the constructor, like the reference (model.py:486-494)
         self.patch_embedding_2x = _pyramid_conv(self.patch_embedding, (1, 4, 4))
@@ -137,11 +187,67 @@ class WanModel(nn.Module):
     def dtype(self):
         return self.patch_embedding.weight.dtype
 
+    def _bind_blocks(self):
+        for i, blk in enumerate(self.blocks):
+            blk._bind(self, i)
+
+    # ---- diffusers ModelMixin / ConfigMixin surface the drivers use (wan23/textimage2video.py:143-158, wan/text2video.py:84) ----
+    config_name = "config.json"
+    weights_name = "diffusion_pytorch_model.safetensors"
+
     @classmethod
     def from_config(cls, config, **kw):
-        cfg = {k: v for k, v in dict(config).items() if k in cls.__init__.__code__.co_varnames}
+        cfg = {k: v for k, v in dict(config).items() if k in cls.__init__.__code__.co_varnames and not k.startswith("_")}
         cfg.update(kw)
         return cls(**cfg)
+
+    @classmethod
+    def from_pretrained(cls, pretrained_model_name_or_path, subfolder=None, torch_dtype=None, device=None, **kw):
+        """Build from `<dir>/config.json` and load `<dir>/diffusion_pytorch_model.safetensors` (or its sharded
+        `...safetensors.index.json` form, or a `.bin` / `.pth` pickle) — the on-disk layout diffusers' ModelMixin writes and
+        the Yume checkpoints ship in. Tensors are streamed shard by shard straight onto `device` (safetensors' lazy
+        `safe_open`), never materialising a second full copy on the host (fastvideo/utils/checkpoint.py:285-337 does the
+        same per-tensor copy for its FSDP load). Keys missing from the file keep their initial value only for the pyramid
+        patch embeddings (derived from the base kernel, as the reference does); anything else missing or unexpected raises."""
+        root = os.fspath(pretrained_model_name_or_path)
+        if subfolder:
+            root = os.path.join(root, subfolder)
+        with open(os.path.join(root, cls.config_name)) as fh:
+            config = json.load(fh)
+        if device is not None:
+            with torch.device(device):
+                model = cls.from_config(config, **kw)
+        else:
+            model = cls.from_config(config, **kw)
+        if torch_dtype is not None:
+            model = model.to(torch_dtype)
+        from ...checkpoint import stream_state_dict
+        missing, unexpected = stream_state_dict(model, root, cls.weights_name)
+        derived = [k for k in missing if k.startswith("patch_embedding_")]
+        hard = [k for k in missing if k not in derived]
+        if hard or unexpected:
+            raise RuntimeError(f"{root}: missing keys {hard[:8]}{'...' if len(hard) > 8 else ''}, "
+                               f"unexpected keys {unexpected[:8]}{'...' if len(unexpected) > 8 else ''}")
+        if derived and any(k.startswith("patch_embedding_2x.") for k in derived):
+            model._rebuild_pyramid()
+        return model.eval()
+
+    def save_pretrained(self, save_directory, max_shard_size=10 << 30, safe_serialization=True):
+        """config.json + safetensors shards (+ index) in the layout from_pretrained / diffusers read."""
+        from ...checkpoint import save_sharded
+        os.makedirs(save_directory, exist_ok=True)
+        cfg = {"_class_name": type(self).__name__, "_diffusers_version": "0.33.0"}
+        cfg.update({k: (list(v) if isinstance(v, tuple) else v) for k, v in self.config.items()})
+        with open(os.path.join(save_directory, self.config_name), "w") as fh:
+            json.dump(cfg, fh, indent=2, sort_keys=True)
+        save_sharded(self.state_dict(), save_directory, self.weights_name, max_shard_size)
+
+    def _rebuild_pyramid(self):
+        for name, size in (("patch_embedding_2x", (1, 4, 4)), ("patch_embedding_4x", (1, 8, 8)),
+                           ("patch_embedding_8x", (1, 16, 16)), ("patch_embedding_16x", (1, 32, 32))):
+            if hasattr(self, name):
+                setattr(self, name, _pyramid_conv(self.patch_embedding, size).to(self.patch_embedding.weight.device,
+                                                                                 self.patch_embedding.weight.dtype))
 
     def init_weights(self):
         """same distributions as reference model.py:892-914 (xavier Linear, N(0,.02) embeddings, zero head)."""
@@ -161,7 +267,18 @@ class WanModel(nn.Module):
     def engine(self):
         if self._engine is None:
             self._engine = DiTEngine(self, self._family)
+            self._bind_blocks()
         return self._engine
+
+    def __getstate__(self):
+        # copies / pickles of the module must not drag the engine (device workspaces, packed weights) along
+        st = dict(self.__dict__)
+        st["_engine"] = None
+        return st
+
+    def __setstate__(self, st):
+        self.__dict__.update(st)
+        self._bind_blocks()
 
     def enable_sequence_parallel(self, group=None):
         """Split every following forward's tokens over the ranks of `group` (Ulysses all-to-all around the

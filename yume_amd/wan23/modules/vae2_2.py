@@ -28,7 +28,7 @@ _STD = [0.4765, 1.0364, 0.4514, 1.1677, 0.5313, 0.4990, 0.4818, 0.5013, 0.8158, 
 
 class _VaeBase(nn.Module):
     """shared by the 2.2 and 2.1 drop-ins: parameter tree + engine + the reference's encode/decode(x, scale) surface."""
-    _version = "2.2"
+    _vae_version = "2.2"
 
     def _setup(self, cfg):
         self.cfg = cfg
