@@ -40,7 +40,7 @@ def test_sequence_lengths_of_the_long_video_loop():
     assert framepack.pack_plan(17, 68, 120, 9, 17 - 9).seq_len == 27810   # 14B 65-frame clip
 
 
-@pytest.mark.parametrize("F,H,W,lfz", [(13, 12, 16, 8), (21, 44, 80, 8), (40, 10, 14, 8), (110, 9, 11, 8), (14, 12, 16, 9)])
+@pytest.mark.parametrize("F,H,W,lfz", [(13, 12, 16, 8), (21, 44, 80, 8), (40, 10, 14, 8), (110, 10, 14, 8), (110, 6, 10, 8), (14, 12, 16, 9)])
 def test_rope_table_matches_oracle(F, H, W, lfz):
     plan = framepack.pack_plan(F, H, W, lfz)
     cs = framepack.plan_rope(plan, 128)                      # [L, 64, 2] fp32
