@@ -106,7 +106,7 @@ def vae_decode_rate(dev, z8):
 
 def vae_cpu_baseline():
     """north_star: "VAE decode latents/sec, vs CPU reference". The oracle decoder (oracle/vae.py, fp32, pinned to the reference) on
-    the host cores at a reduced spatial size — 2 latents [48,2,16,24] instead of [48,8,44,80] — with its FLOPs counted by torch's
+    the host cores at a reduced spatial size — 2 latents [48,2,6,10] instead of [48,8,44,80] — with its FLOPs counted by torch's
     FlopCounterMode; the full-size rate is that FLOP rate divided by the 485.04/8 TFLOP one full-size latent costs."""
     from torch.utils.flop_counter import FlopCounterMode
     from oracle import vae as ovae
@@ -114,7 +114,7 @@ def vae_cpu_baseline():
     torch.set_num_threads(os.cpu_count() or 1)
     cfg = synth.VAE_CFG_22
     sd = synth.make_vae_state_dict(cfg, seed=5)
-    z = torch.randn(48, 2, 16, 24, generator=torch.Generator().manual_seed(6))
+    z = torch.randn(48, 2, 6, 10, generator=torch.Generator().manual_seed(6))
     with FlopCounterMode(display=False) as fc:
         t0 = time.time()
         out = ovae.decode(sd, cfg, z)
@@ -122,7 +122,7 @@ def vae_cpu_baseline():
     assert torch.isfinite(out).all()
     tf = fc.get_total_flops() / 1e12
     return {"value": (tf / dt) / (485.04 / 8.0), "unit": "latents/s", "cores": os.cpu_count(), "kind": "port",
-            "sample": f"oracle decode of 2 latents 48x2x16x24 ({tf:.2f} TFLOP, {dt:.2f} s = {tf / dt:.2f} TFLOP/s fp32), "
+            "sample": f"oracle decode of 2 latents 48x2x6x10 ({tf:.2f} TFLOP, {dt:.2f} s = {tf / dt:.2f} TFLOP/s fp32), "
                       "scaled by FLOPs to the 704x1280 chunk (60.6 TFLOP per latent)"}
 
 
