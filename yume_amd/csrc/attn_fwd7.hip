@@ -12,8 +12,9 @@
 //     the MFMAs of a phase never depend on the VALU work beside them, so dependent-latency chains of the softmax hide
 //     under the matrix pipe; one piece (<= ~6 instructions) of the softmax sits in each MFMA gap, written out by hand
 //     (sm_piece<I>) and pinned with sched_barriers;
-//   * the exponentials are taken against the block's running base (deferred rescale, P <= 2^8); the row maximum is reduced
-//     beside them and only decides whether the tile is redone against a new base (first tile; then almost never);
+//   * the exponentials are taken against the block's running base (deferred rescale, P < 2^13); no row maximum is reduced
+//     on that path: a partial row sum above 2^13 (inf on the first tile) is what sends a tile to the redo path, which
+//     takes the maximum from S, rescales O and l and rebuilds the tile (first tile; then almost never);
 //   * O (a[0:127]) and Q^T (a[128:191]) live in AGPRs this file OWNS: they are named literally in inline asm (MFMAs,
 //     v_accvgpr_read/write) and listed as clobbers of every such statement, so hipcc keeps nothing of its own there
 //     (tests/test_attn7_isa.py audits the generated code for that). hipcc's own choice for a 512-register kernel puts
@@ -22,20 +23,15 @@
 //     compiler-managed VGPRs. Hazards the compiler cannot see (MFMA result -> VALU / accvgpr read) are covered by
 //     distance (>= 16 MFMAs) in the pipelined path and by explicit s_nop pads in the rare paths;
 //   * K / V^T tiles arrive by LDS-DMA into 4 + 4 slots of 16 KiB, three tiles ahead, one counted vmcnt + one workgroup
-//     barrier per tile; fragments go through a 4-deep register ring that runs across phase and tile boundaries.
+//     barrier per tile; the 16 K fragments of a tile are read from LDS ONCE into AGPRs a[192:255] (right after their last
+//     reader, one per gap) and feed the S MFMAs of both blocks; V^T fragments go through a 4-deep VGPR ring.
 // LDS images are those of attn_fwd.hip v2/v4 (K: chunk ^ (row & 15); V^T: chunk ^ ((row >> 1) & 7), swizzled on the DMA source).
 // Roofline: MFMA bf16 dense; algorithmic work 4*Lq*Lk*128 flop per head.
 #include "common.hpp"
 #include "attn_args.hpp"
 #include <type_traits>
 
-#ifndef ATTN7_DBG
-#define ATTN7_DBG 0
-#endif
 namespace {
-// timing experiments only (results are garbage when non-zero): 1 no exp, 2 no fragment reads, 4 no DMA, 8 no softmax pieces,
-// 16 no barrier / vmcnt wait, 32 no row-sum adds, 64 no MFMAs, 128 no max pieces, 256 no packing
-constexpr int DBG = ATTN7_DBG;
 
 constexpr int KT = 64;
 constexpr int D = 128;
@@ -44,34 +40,42 @@ constexpr int NS = 4;                     // slots per operand
 constexpr int VB = NS * SLOT;             // V^T slots start here
 constexpr int LDS7 = 2 * NS * SLOT;       // 128 KiB
 constexpr int QB7 = 256;                  // queries per workgroup
-#ifndef ATTN7_RD
-#define ATTN7_RD 4
-#endif
-constexpr int RD = ATTN7_RD;              // fragment ring depth: a fragment is read RD MFMA gaps before its MFMA (power of two)
+constexpr int RD = 4;                     // V^T fragment ring depth: a fragment is read RD MFMA gaps before its MFMA (8 measured the same)
 constexpr float NEG_BIG = -1.0e30f;
-constexpr float DEFER_LOG2 = 8.0f;
+constexpr float OVERFLOW_LOG2 = 13.0f;       // deferred rescale: exponentials stay below 2^13 against the running base
+constexpr float OVERFLOW_SUM = 8192.0f;       // = 2^13: a larger partial row sum (32 exponentials) proves one of them exceeded 2^8
 
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((address_space(1))) const void gbl_cvoid_t;
 
 // ---- the AGPRs this kernel owns -----------------------------------------------------------------------------------------
-//   block A: O^T a[0:63] (d block db at 16*db), Q^T a[128:159] (k-step ks at 4*ks);  block B: O^T a[64:127], Q^T a[160:191]
-constexpr int OA = 0, OB = 64, QA = 128, QB = 160;
+//   block A: O^T a[0:63] (d block db at 16*db), Q^T a[128:159] (k-step ks at 4*ks);  block B: O^T a[64:127], Q^T a[160:191];
+//   a[192:255]: the 16 K fragments of the current key tile (fragment f at 4*f), read from LDS once and used by both blocks
+constexpr int OA = 0, OB = 64, QA = 128, QB = 160, KC0 = 192;
 #define AG8(n) "a" #n "0", "a" #n "1", "a" #n "2", "a" #n "3", "a" #n "4", "a" #n "5", "a" #n "6", "a" #n "7", "a" #n "8", "a" #n "9"
 #define OWNED_AGPRS "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", AG8(1), AG8(2), AG8(3), AG8(4), AG8(5), AG8(6), AG8(7), \
-    AG8(8), AG8(9), AG8(10), AG8(11), AG8(12), AG8(13), AG8(14), AG8(15), AG8(16), AG8(17), AG8(18), "a190", "a191"
+    AG8(8), AG8(9), AG8(10), AG8(11), AG8(12), AG8(13), AG8(14), AG8(15), AG8(16), AG8(17), AG8(18), AG8(19), AG8(20), AG8(21), AG8(22), \
+    AG8(23), AG8(24), "a250", "a251", "a252", "a253", "a254", "a255"
 // S = K Q^T: D in VGPRs (the softmax reads it), A = K fragment (VGPR, from LDS), B = Q^T fragment a[q:q+3]
 // Every MFMA statement also names the softmax state of the OTHER block (Y) as input operands it does not use: that
 // pins the VALU work written in the preceding gap to that gap (LLVM otherwise sinks whatever is only needed after the
 // phase-end redo branch out from under the MFMAs) without separate statements — an empty asm right behind a VALU write
 // costs an s_nop each time.
 #define YPINS(y) "v"(y.z.x), "v"(y.z.p[0]), "v"(y.z.p[1]), "v"(y.z.p[2]), "v"(y.z.p[3]), "v"(y.z.p[4]), "v"(y.z.p[5]), "v"(y.z.p[6]), "v"(y.z.p[7]), \
-    "v"(y.z.sum0), "v"(y.z.sum1), "v"(y.z.mx), "v"(y.z.ev), "v"(y.z.od), "v"(y.z.w0), "v"(y.z.w1)
+    "v"(y.z.sum0), "v"(y.z.sum1), "v"(y.z.ev), "v"(y.z.od), "v"(y.z.w0), "v"(y.z.w1)
 #define MFMA_S0(d, a, q, y) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, a[%c2:%c3], 0" : "=&v"(d) : "v"(a), "n"(q), "n"((q) + 3), YPINS(y) : "memory", OWNED_AGPRS)
 #define MFMA_S(d, a, q, y) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, a[%c2:%c3], %0" : "+v"(d) : "v"(a), "n"(q), "n"((q) + 3), YPINS(y) : "memory", OWNED_AGPRS)
 // O += V^T P^T: C/D = a[o:o+15], A = V^T fragment (VGPR, from LDS), B = P^T fragment (VGPR)
 #define MFMA_O(o, a, b, y) asm volatile("v_mfma_f32_32x32x16_bf16 a[%c2:%c3], %0, %1, a[%c2:%c3]" ::"v"(a), "v"(b), "n"(o), "n"((o) + 15), YPINS(y) : "memory", OWNED_AGPRS)
 #define PIN_BLK(y) asm volatile("" ::YPINS(y))
+// the same S MFMAs with the K fragment taken from the cache a[k:k+3]
+#define MFMA_S0_KC(d, k, q, y) asm volatile("v_mfma_f32_32x32x16_bf16 %0, a[%c1:%c2], a[%c3:%c4], 0" : "=&v"(d) : "n"(k), "n"((k) + 3), "n"(q), "n"((q) + 3), YPINS(y) : "memory", OWNED_AGPRS)
+#define MFMA_S_KC(d, k, q, y) asm volatile("v_mfma_f32_32x32x16_bf16 %0, a[%c1:%c2], a[%c3:%c4], %0" : "+v"(d) : "n"(k), "n"((k) + 3), "n"(q), "n"((q) + 3), YPINS(y) : "memory", OWNED_AGPRS)
+// K fragment F (k-step F>>1, key half F&1) of the K slot at LDS byte offset kb -> a[KC0 + 4F ..]. Untracked by hipcc's s_waitcnt
+// bookkeeping: LDS returns in order, and every such load is followed by V^T fragment reads hipcc does wait for before the
+// phase ends (or by an explicit s_waitcnt lgkmcnt(0) where it is not), so the data is there when the next phase's MFMAs read it.
+#define LOAD_KC(F, addr, off) asm volatile("ds_read_b128 a[%c1:%c2], %0 offset:%c3" ::"v"(addr), "n"(KC0 + 4 * (F)), "n"(KC0 + 4 * (F) + 3), "n"(off) : "memory", OWNED_AGPRS)
+#define LOAD_KC_DYN(F, addr, off) LOAD_KC(F, addr, off)
 template <int R>
 __device__ __forceinline__ void agpr_set(unsigned v) {
     asm volatile("v_accvgpr_write_b32 a[%c1], %0" ::"v"(v), "n"(R) : OWNED_AGPRS);
@@ -124,13 +128,11 @@ struct Soft {
     float x;            // shifted score of the element whose exponential comes next
     float p[8];         // exponentials not yet packed
     float sum0, sum1;   // partial row sums of the current tile
-    float mx;           // max of the raw scores of the current tile
     unsigned ev, od;    // packed pair waiting for its cross-half swap
     unsigned w0, w1;    // the two P^T words the last swap produced (copies of what went into pf; only there to be pinned)
-    float m_new;        // candidate exponent base
     float m_run;        // exponent base in use (log2 domain)
     float l_run;        // row sum over this lane's keys
-    int need;           // wave-uniform: the tile has to be redone against m_new
+    int need;           // wave-uniform: the tile has to be redone against a new base
 };
 struct Blk {             // the compiler-managed part of a block (O^T and Q^T are in the owned AGPRs)
     f32x16 s[2];        // S^T of one key tile
@@ -144,20 +146,20 @@ struct Blk {             // the compiler-managed part of a block (O^T and Q^T ar
 //   I = e + 2  : row sum                                     (I = 2..33)
 //   I = 8g + 9 .. 8g + 11 : pack the 8 exponentials of group g into the P^T fragment g: cvt_pk pair 0 | swap 0, cvt_pk pair 1 |
 //                swap 1 (a v_permlane32_swap right behind the cvt_pk that feeds it needs two idle states)
-//   I = 0..15  : running max of the raw scores, I = 16 cross-half, I = 17 candidate base + wave vote
+//   I = 31     : wave vote: did any partial row sum leave the range the running base guarantees? (no row maximum on this path)
 //   I = 35     : l += sums
 // Pieces 0..31 sit in the 32 MFMA gaps of the phase that computes the OTHER block; 32..35 ("drain") sit in the first four
 // gaps of the next phase. Re-running pieces 0..31 rebuilds exactly the state the drain expects (the redo path).
 template <int I, bool MASK>
 __device__ __forceinline__ void sm_piece(Soft& z, const f32x16 (&s)[2], u32x4 (&pf)[4], float c, int keyb, int Lk) {
-    if constexpr (I >= 2 && I <= 33 && !(DBG & 32)) {
+    if constexpr (I >= 2 && I <= 33) {
         constexpr int e = I - 2;
         if constexpr (e == 0) z.sum0 = z.p[0];
         else if constexpr (e == 1) z.sum1 = z.p[1];
         else if constexpr ((e & 1) != 0) z.sum1 += z.p[e & 7];
         else z.sum0 += z.p[e & 7];
     }
-    if constexpr (I >= 9 && !(DBG & 256)) {
+    if constexpr (I >= 9) {
         constexpr int g = (I - 9) >> 3, k = (I - 9) & 7;
         if constexpr (k == 1 || k == 2) {          // swap of pair k - 1
             const auto r = __builtin_amdgcn_permlane32_swap(z.ev, z.od, false, false);
@@ -174,7 +176,7 @@ __device__ __forceinline__ void sm_piece(Soft& z, const f32x16 (&s)[2], u32x4 (&
     }
     if constexpr (I >= 1 && I <= 32) {
         constexpr int e = I - 1;
-        float pv = (DBG & 1) ? z.x : __builtin_amdgcn_exp2f(z.x);
+        float pv = __builtin_amdgcn_exp2f(z.x);
         if constexpr (MASK) {
             constexpr int b = e >> 4, r = e & 15;
             const int key = keyb + 32 * b + (r & 3) + 8 * (r >> 2);
@@ -183,17 +185,12 @@ __device__ __forceinline__ void sm_piece(Soft& z, const f32x16 (&s)[2], u32x4 (&
         z.p[e & 7] = pv;
     }
     if constexpr (I <= 31) z.x = __builtin_fmaf(s[I >> 4][I & 15], c, -z.m_run);
-    if constexpr (DBG & 128) {
-    } else if constexpr (I == 0) {
-        z.mx = max2f(s[0][0], s[0][1]);
-    } else if constexpr (I <= 15) {
-        constexpr int e = 2 * I;
-        z.mx = max3f(z.mx, s[e >> 4][e & 15], s[e >> 4][(e & 15) + 1]);
-    } else if constexpr (I == 16) {
-        z.mx = xhalf_max(z.mx);
-    } else if constexpr (I == 17) {
-        z.m_new = max2f(z.m_run, z.mx * c);
-        z.need = !__all(z.m_new - z.m_run <= DEFER_LOG2);
+    if constexpr (I == 31) {
+        // Did the base hold? The exponentials of a tile whose scores exceed the running base by more than 2^13 make the row sum
+        // (or the two values not yet summed) exceed 2^13 — including inf on the first tile, whose base is -1e30. No row maximum
+        // is reduced on this path; the redo path computes it from S, which stays intact until the next phase.
+        const float big = max3f(z.sum0, z.sum1, z.p[30 & 7]);
+        z.need = __any((big > OVERFLOW_SUM) | (z.x > OVERFLOW_LOG2));
     }
     if constexpr (I == 35) z.l_run += z.sum0 + z.sum1;
 }
@@ -201,12 +198,19 @@ __device__ __forceinline__ void sm_piece(Soft& z, const f32x16 (&s)[2], u32x4 (&
 #define REP32(M) M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7) M(8) M(9) M(10) M(11) M(12) M(13) M(14) M(15) \
                  M(16) M(17) M(18) M(19) M(20) M(21) M(22) M(23) M(24) M(25) M(26) M(27) M(28) M(29) M(30) M(31)
 
-// the tile of block y (O^T at a[YO:YO+63]) has to be redone against y.z.m_new: rescale what was accumulated, rebuild the softmax state
+// the tile of block y (O^T at a[YO:YO+63]) has to be redone against a new base (the row maximum, taken here): rescale what was accumulated, rebuild the softmax state
 template <int YO, bool MASK>
 __device__ __forceinline__ void redo_tile(Blk& y, float c, int keyb, int Lk) {
     NOP_PAD();                                          // pending MFMA results -> accvgpr reads
-    const float alpha = __builtin_amdgcn_exp2f(y.z.m_run - y.z.m_new);
-    y.z.m_run = y.z.m_new;
+    float mx = y.s[0][0];
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, y.s[b][r]);       // rows >= Lk of a ragged K tile are copies of a valid key: no mask needed
+    mx = xhalf_max(mx);
+    const float m_new = fmaxf(y.z.m_run, mx * c);
+    const float alpha = __builtin_amdgcn_exp2f(y.z.m_run - m_new);
+    y.z.m_run = m_new;
     y.z.l_run *= alpha;
     for_regs<YO, 64>([&](auto r) { agpr_scale<decltype(r)::value>(alpha); });
 #define YUME_P(i) sm_piece<i, MASK>(y.z, y.s, y.pf, c, keyb, Lk);
@@ -265,12 +269,13 @@ __device__ __forceinline__ void dma7_k(const Dma7& d, const AttnArgs& p, int t, 
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) glds16(base, d.kof[rr], l + rr * 4096);
     } else {
-        const int nrow = p.Lk - t * KT;       // 1..63 valid rows; the others are copies of the last one (their P is masked)
+        int nrow = p.Lk - t * KT;             // 1..63 valid rows; the others are copies of the last one (their P is masked)
+        asm volatile("" : "+s"(nrow));        // rare path: keep its address arithmetic here instead of hoisted (and spilled) in front of the tile loop
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
             const int r = d.kr + 16 * rr;
             const int rc = r < nrow ? r : nrow - 1;
-            glds16(base, (unsigned)(rc * d.krow) + d.kch, l + rr * 4096);
+            glds16(base, (unsigned)rc * (unsigned)d.krow + (unsigned)d.kch, l + rr * 4096);
         }
     }
 }
@@ -279,7 +284,8 @@ __device__ __forceinline__ void dma7_v(const Dma7& d, const AttnArgs& p, int t, 
     const unsigned l = slot + wave * 1024;
     unsigned back = 0;
     if (last_ragged) {
-        const int kc = t * KT + d.vc * 8;
+        int kc = t * KT + d.vc * 8;
+        asm volatile("" : "+v"(kc));          // rare path: not hoisted
         const int kmax = (int)p.ldvt - 8;
         if (kc > kmax) back = (unsigned)((kc - kmax) * 2);         // stay inside the row; such a chunk is zeroed afterwards
     }
@@ -288,7 +294,8 @@ __device__ __forceinline__ void dma7_v(const Dma7& d, const AttnArgs& p, int t, 
 }
 // keys >= Lk of the ragged last V^T tile -> 0 (0 * stale bits must be 0), by the thread whose DMA brought the chunk
 __device__ __forceinline__ void fix7_v(const Dma7& d, const AttnArgs& p, int t, char* slot, int tid) {
-    const int nvalid = p.Lk - (t * KT + d.vc * 8);
+    int nvalid = p.Lk - (t * KT + d.vc * 8);
+    asm volatile("" : "+v"(nvalid));          // rare path (once per workgroup): its lane masks are not worth registers across the tile loop
     if (nvalid >= 8) return;
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) {
@@ -314,62 +321,55 @@ struct Ctx {
     int wave;
 };
 
-// fragment F of a phase: F < 16 -> K fragment (k-step F>>1, key half F&1) of the slot at kb; else V^T fragment
-// (key group (F-16)>>2, d block (F-16)&3) of the slot at vb
+// V^T fragment F - 16 (key group (F-16)>>2, d block (F-16)&3) of the V^T slot at byte offset vb (F = 16..31: the MFMA gap that uses it)
 template <int F>
-__device__ __forceinline__ u32x4 frag(const Ctx& cx, int kb, int vb) {
-    if constexpr (F < 16)
-        return *reinterpret_cast<const u32x4*>(cx.smem + kb + cx.koff[F >> 1] + (F & 1) * (32 * 256));
-    else
-        return *reinterpret_cast<const u32x4*>(cx.smem + vb + cx.voff[(F - 16) >> 2] + ((F - 16) & 3) * (32 * 128));
+__device__ __forceinline__ u32x4 frag(const Ctx& cx, int vb) {
+    static_assert(F >= 16 && F < 32, "V^T fragments belong to gaps 16..31");
+    return *reinterpret_cast<const u32x4*>(cx.smem + vb + cx.voff[(F - 16) >> 2] + ((F - 16) & 3) * (32 * 128));
 }
 
-// X (O^T at a[XO..], Q^T at a[XQ..]): the block whose MFMAs run (S of the tile in K slot kb if DO_S, O += V^T P of the tile in V slot vb if DO_PV) and whose
-//    previous softmax drains in the first gaps (DRAIN, tile starting at key jx);
+// all 16 K fragments of the K slot at byte offset kb -> the AGPR cache, and wait for them (prologue / before the steady loop)
+__device__ __forceinline__ void fill_kcache(const Ctx& cx, int kb) {
+#define YUME_KC(f) LOAD_KC_DYN(f, cx.koff[(f) >> 1] + kb, ((f) & 1) ? 32 * 256 : 0);
+    YUME_KC(0) YUME_KC(1) YUME_KC(2) YUME_KC(3) YUME_KC(4) YUME_KC(5) YUME_KC(6) YUME_KC(7)
+    YUME_KC(8) YUME_KC(9) YUME_KC(10) YUME_KC(11) YUME_KC(12) YUME_KC(13) YUME_KC(14) YUME_KC(15)
+#undef YUME_KC
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
+
+// X (O^T at a[XO..], Q^T at a[XQ..]): the block whose MFMAs run — S of the K tile in the AGPR cache if DO_S, O += V^T P of the tile in
+//    V^T slot vb if DO_PV — and whose previous softmax drains in the first gaps (DRAIN, tile starting at key jx);
 // Y (O^T at a[YO..]): the block whose softmax pieces fill the gaps (SM, tile starting at key jy).
-// CIN: the ring already holds this phase's first RD fragments; COUT: the last RD gaps fetch K fragments 0..RD-1 of slot nkb.
+// NKB >= 0: refill the K cache with the K slot at byte offset NKB (compile-time: it folds into the ds_read offsets), fragment f in
+//   gap f + 1, right after its last reader in this phase.
 // DMA: gaps 0..7 issue one LDS-DMA piece each (K tile at kg -> kslot, V^T tile at vg -> vslot).
-template <int XO, int XQ, int YO, bool DO_S, bool DO_PV, bool DRAIN, bool MASKX, bool SM, bool MASKY, bool DMA, bool CIN, bool COUT>
-__device__ __forceinline__ void phase(const Ctx& cx, Blk& X, Blk& Y, u32x4 (&ring)[RD], int kb, int vb, int nkb, int jx, int jy,
+template <int XO, int XQ, int YO, bool DO_S, bool DO_PV, bool DRAIN, bool MASKX, bool SM, bool MASKY, bool DMA, int NKB = -1>
+__device__ __forceinline__ void phase(const Ctx& cx, Blk& X, Blk& Y, u32x4 (&ring)[RD], int vb, int jx, int jy,
                                       const Dma7& dp, const char* kg, const char* vg, unsigned kslot, unsigned vslot) {
-    constexpr int F0 = DO_S ? 0 : 16;
-    if constexpr (!CIN && (DO_S || DO_PV)) {
-        ring[0] = frag<F0 + 0>(cx, kb, vb);
-        ring[1] = frag<F0 + 1>(cx, kb, vb);
-        ring[2] = frag<F0 + 2>(cx, kb, vb);
-        ring[3] = frag<F0 + 3>(cx, kb, vb);
-        if constexpr (RD == 8) {
-            ring[4] = frag<F0 + 4>(cx, kb, vb);
-            ring[5] = frag<F0 + 5>(cx, kb, vb);
-            ring[6] = frag<F0 + 6>(cx, kb, vb);
-            ring[7] = frag<F0 + 7>(cx, kb, vb);
-        }
-    }
     __builtin_amdgcn_sched_barrier(0);
 #define YUME_GAP(i)                                                                                          \
     {                                                                                                        \
         if constexpr (SM && ((i) < 16 ? !DO_S : !DO_PV)) PIN_BLK(Y);                                         \
         if constexpr ((i) < 16) {                                                                            \
-            if constexpr (DO_S && !(DBG & 64)) {                                                             \
-                if constexpr (((i) >> 1) == 0) MFMA_S0(X.s[(i) & 1], ring[(i) & (RD - 1)], XQ, Y);                 \
-                else MFMA_S(X.s[(i) & 1], ring[(i) & (RD - 1)], XQ + 4 * ((i) >> 1), Y);                                     \
+            if constexpr (DO_S) {                                                             \
+                if constexpr (((i) >> 1) == 0) MFMA_S0_KC(X.s[(i) & 1], KC0 + 4 * ((i) & 15), XQ, Y);        \
+                else MFMA_S_KC(X.s[(i) & 1], KC0 + 4 * ((i) & 15), XQ + 4 * ((i) >> 1), Y);                  \
             }                                                                                                \
-        } else if constexpr (DO_PV && !(DBG & 64)) {                                                         \
-            MFMA_O(XO + 16 * (((i) - 16) & 3), ring[(i) & (RD - 1)], X.pf[((i) - 16) >> 2], Y);                               \
+        } else if constexpr (DO_PV) {                                                         \
+            MFMA_O(XO + 16 * (((i) - 16) & 3), ring[(i) & (RD - 1)], X.pf[((i) - 16) >> 2], Y);              \
         }                                                                                                    \
-        if constexpr ((i) + RD < 32) {                                                                       \
-            if constexpr (((i) + RD >= 16 ? DO_PV : DO_S) && !(DBG & 2)) ring[(i) & (RD - 1)] = frag<((i) + RD) & 31>(cx, kb, vb); \
-        } else if constexpr (COUT && !(DBG & 2)) {                                                           \
-            ring[(i) & (RD - 1)] = frag<((i) + RD) & 15>(cx, nkb, 0);                                        \
-        }                                                                                                    \
-        if constexpr (DMA && (i) < 8 && !(DBG & 4)) dma7_piece<(i) & 7>(dp, kg, vg, kslot, vslot, cx.wave);                \
-        if constexpr (DRAIN && (i) >= 1 && (i) < 5 && !(DBG & 8)) PIN_BLK(X);     /* drain piece of the previous gap stays there */ \
-        if constexpr (DRAIN && (i) < 4 && !(DBG & 8)) sm_piece<32 + ((i) & 3), MASKX>(X.z, X.s, X.pf, cx.c, jx + cx.keyh, cx.Lk); \
-        if constexpr (SM && !(DBG & 8)) sm_piece<(i), MASKY>(Y.z, Y.s, Y.pf, cx.c, jy + cx.keyh, cx.Lk);                   \
+        if constexpr (DO_PV && (i) + RD >= 16 && (i) + RD < 32) ring[(i) & (RD - 1)] = frag<(((i) + RD) & 15) + 16>(cx, vb); \
+        if constexpr (NKB >= 0 && (i) >= 1 && (i) <= 16)                                       \
+            LOAD_KC(((i) - 1) & 15, cx.koff[(((i) - 1) & 15) >> 1], (NKB < 0 ? 0 : NKB) + ((((i) - 1) & 1) ? 32 * 256 : 0)); \
+        if constexpr (DMA && (i) < 8) dma7_piece<(i) & 7>(dp, kg, vg, kslot, vslot, cx.wave);  \
+        if constexpr (DRAIN && (i) >= 1 && (i) < 5) PIN_BLK(X);     /* drain piece of the previous gap stays there */ \
+        if constexpr (DRAIN && (i) < 4) sm_piece<32 + ((i) & 3), MASKX>(X.z, X.s, X.pf, cx.c, jx + cx.keyh, cx.Lk); \
+        if constexpr (SM) sm_piece<(i), MASKY>(Y.z, Y.s, Y.pf, cx.c, jy + cx.keyh, cx.Lk);     \
         __builtin_amdgcn_sched_barrier(0);                                                                   \
     }
     REP32(YUME_GAP)
 #undef YUME_GAP
+    if constexpr (NKB >= 0 && !DO_PV) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // no V^T reads behind the K loads to order them
     if constexpr (SM) {
         PIN_BLK(Y);
         if (__builtin_expect(Y.z.need, 0)) redo_tile<YO, MASKY>(Y, cx.c, jy + cx.keyh, cx.Lk);
@@ -421,9 +421,7 @@ __device__ __forceinline__ void load_q(const AttnArgs& p, Blk& x, int q, int h, 
     x.z.need = 0;
     x.z.sum0 = x.z.sum1 = 0.f;
     x.z.x = 0.f;
-    x.z.mx = 0.f;
     x.z.ev = x.z.od = x.z.w0 = x.z.w1 = 0u;
-    x.z.m_new = NEG_BIG;
 #pragma unroll
     for (int i = 0; i < 8; ++i) x.z.p[i] = 0.f;
 }
@@ -431,17 +429,15 @@ __device__ __forceinline__ void load_q(const AttnArgs& p, Blk& x, int q, int h, 
 // steady-state tile t (TS = t % 4): 1 <= t, t + 4 < number of FULL tiles; every LDS address is a compile-time constant
 template <int TS>
 __device__ __forceinline__ void steady7(const Ctx& cx, const Dma7& dp, int t, Blk& A, Blk& B, u32x4 (&ring)[RD]) {
-    constexpr int kb = ((TS + 1) & 3) * SLOT, vb = TS * SLOT, nkb = ((TS + 2) & 3) * SLOT;
+    constexpr int vb = TS * SLOT, nkb = ((TS + 2) & 3) * SLOT;      // V^T(t); K(t+2) for the cache refill (K(t+1) is in the cache)
     const char* kg = dp.kbase + (int64_t)(t + 4) * KT * dp.krow;
     const char* vg = dp.vbase + (int64_t)(t + 3) * KT * 2;
     const unsigned kslot = cx.lds0 + TS * SLOT;
     const unsigned vslot = cx.lds0 + VB + ((TS + 3) & 3) * SLOT;
-    if constexpr (!(DBG & 16)) {
-        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");      // everything older than the previous tile's 8 pieces has landed
-        __builtin_amdgcn_s_barrier();
-    }
-    phase<OA, QA, OB, true, true, true, false, true, false, true, true, true>(cx, A, B, ring, kb, vb, kb, 0, 0, dp, kg, vg, kslot, vslot);
-    phase<OB, QB, OA, true, true, true, false, true, false, false, true, true>(cx, B, A, ring, kb, vb, nkb, 0, 0, dp, kg, vg, kslot, vslot);
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");      // everything older than the previous tile's 8 pieces has landed
+    __builtin_amdgcn_s_barrier();
+    phase<OA, QA, OB, true, true, true, false, true, false, true>(cx, A, B, ring, vb, 0, 0, dp, kg, vg, kslot, vslot);
+    phase<OB, QB, OA, true, true, true, false, true, false, false, nkb>(cx, B, A, ring, vb, 0, 0, dp, kg, vg, kslot, vslot);
 }
 
 // any tile t of the range [.., t1) (runtime slots; the softmax pieces always carry the key mask). nt / ragged describe the whole key
@@ -455,14 +451,15 @@ __device__ __forceinline__ void general7(const Ctx& cx, const Dma7& dp, const At
     __builtin_amdgcn_s_barrier();
     if (t + 4 < t1) dma7_k(dp, p, t + 4, ragged && t + 4 == last, cx.lds0 + ((t + 4) & 3) * SLOT, cx.wave);
     if (t + 3 < t1) dma7_v(dp, p, t + 3, ragged && t + 3 == last, cx.lds0 + VB + ((t + 3) & 3) * SLOT, cx.wave);
-    const int kb = ((t + 1) & 3) * SLOT, vb = (t & 3) * SLOT;
+    const int vb = (t & 3) * SLOT;
     const int j = t * KT;
     if (t + 1 < t1) {
-        phase<OA, QA, OB, true, true, true, true, true, true, false, false, false>(cx, A, B, ring, kb, vb, 0, j, j, dp, nullptr, nullptr, 0u, 0u);
-        phase<OB, QB, OA, true, true, true, true, true, true, false, false, false>(cx, B, A, ring, kb, vb, 0, j, j + KT, dp, nullptr, nullptr, 0u, 0u);
+        fill_kcache(cx, ((t + 1) & 3) * SLOT);            // K(t+1), published by the barrier above
+        phase<OA, QA, OB, true, true, true, true, true, true, false>(cx, A, B, ring, vb, j, j, dp, nullptr, nullptr, 0u, 0u);
+        phase<OB, QB, OA, true, true, true, true, true, true, false>(cx, B, A, ring, vb, j, j + KT, dp, nullptr, nullptr, 0u, 0u);
     } else {
-        phase<OA, QA, OB, false, true, true, true, true, true, false, false, false>(cx, A, B, ring, kb, vb, 0, j, j, dp, nullptr, nullptr, 0u, 0u);
-        phase<OB, QB, OA, false, true, true, true, false, true, false, false, false>(cx, B, A, ring, kb, vb, 0, j, j, dp, nullptr, nullptr, 0u, 0u);
+        phase<OA, QA, OB, false, true, true, true, true, true, false>(cx, A, B, ring, vb, j, j, dp, nullptr, nullptr, 0u, 0u);
+        phase<OB, QB, OA, false, true, true, true, false, true, false>(cx, B, A, ring, vb, j, j, dp, nullptr, nullptr, 0u, 0u);
     }
 }
 
@@ -560,26 +557,21 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_kernel_v7(AttnArgs p) {
     u32x4 ring[RD];
     // S_A(t0), then S_B(t0) beside softmax_A(t0)
     {
-        const int kb0 = (t0 & 3) * SLOT, j0 = t0 * KT;
-        phase<OA, QA, OB, true, false, false, true, false, true, false, false, false>(cx, A, B, ring, kb0, 0, 0, j0, j0, dp, nullptr, nullptr, 0u, 0u);
-        phase<OB, QB, OA, true, false, false, true, true, true, false, false, false>(cx, B, A, ring, kb0, 0, 0, j0, j0, dp, nullptr, nullptr, 0u, 0u);
+        const int j0 = t0 * KT;
+        fill_kcache(cx, (t0 & 3) * SLOT);
+        phase<OA, QA, OB, true, false, false, true, false, true, false>(cx, A, B, ring, 0, j0, j0, dp, nullptr, nullptr, 0u, 0u);
+        phase<OB, QB, OA, true, false, false, true, true, true, false>(cx, B, A, ring, 0, j0, j0, dp, nullptr, nullptr, 0u, 0u);
     }
 
     int t = t0;
 #pragma unroll 1
     while (t < t1) {
         if (t > t0 && (t & 3) == 1 && t + 7 < tsteady) {
-            // first fragments of phase 1(t): K(t+1) in slot 2, published by the barrier of the previous tile
-            ring[0] = frag<0>(cx, 2 * SLOT, 0);
-            ring[1] = frag<1>(cx, 2 * SLOT, 0);
-            ring[2] = frag<2>(cx, 2 * SLOT, 0);
-            ring[3] = frag<3>(cx, 2 * SLOT, 0);
-            if constexpr (RD == 8) {
-                ring[4] = frag<4>(cx, 2 * SLOT, 0);
-                ring[5] = frag<5>(cx, 2 * SLOT, 0);
-                ring[6] = frag<6>(cx, 2 * SLOT, 0);
-                ring[7] = frag<7>(cx, 2 * SLOT, 0);
-            }
+            fill_kcache(cx, 2 * SLOT);          // K(t+1) (slot 2 here), published by the barrier of the previous tile
+            // A's score registers are dead here and the loop's first MFMAs overwrite them. Claim them NOW: if hipcc parked a spill
+            // reload in them on the way here, its wait for that load lands in front of the loop instead of inside it, where an
+            // s_waitcnt vmcnt(0) would also wait for every LDS-DMA piece in flight (tests/test_attn7_isa.py checks the loop).
+            asm volatile("" : "=v"(A.s[0]), "=v"(A.s[1]));
 #pragma unroll 1
             for (; t + 7 < tsteady; t += 4) {        // t % 4 == 1; the four calls issue tiles up to t + 7 (all full, all in range)
                 steady7<1>(cx, dp, t, A, B, ring);
