@@ -579,7 +579,9 @@ __device__ __forceinline__ void gemm256_body(const Problem& p, ALoad& al, const 
                 }
 }
 
-// (a v_mfma_f32_32x32x16_bf16 variant of this schedule was built and measured: 13 % slower — dropped)
+// (built, parity-green and measured slower, see profiles/r2_rejected_experiments.md: a v_mfma_f32_32x32x16_bf16 main loop (r1, -13 %); the
+// fragment reads software-pipelined one phase ahead with ping-pong register sets (-1...-15 %); a one-wave-per-SIMD kernel with all
+// 256 AGPRs as accumulators, K tiles of 32 and 0.5 ds_read per MFMA (-13...-20 %))
 
 template <int EPI, class ALoad, int MODE>
 __global__ __launch_bounds__(NTHR256, 2) void gemm256_kernel(Problem p, ALoad al, Epilogue e) {
@@ -599,10 +601,8 @@ __global__ __launch_bounds__(NTHR256, 2) void gemm256_kernel(Problem p, ALoad al
     const int tm = first_m + (wg % width) % gsz;
     const int tn = (wg % width) / gsz;
     const int m0 = tm * 256, n0 = tn * 256;
-    if (EPI == YUME_EPI_BF16_SPLITT && n0 >= e.n_split)
-        gemm256_body<EPI, ALoad, MODE, false>(p, al, e, smem, m0, n0);
-    else
-        gemm256_body<EPI, ALoad, MODE, true>(p, al, e, smem, m0, n0);
+    if (EPI == YUME_EPI_BF16_SPLITT && n0 >= e.n_split) gemm256_body<EPI, ALoad, MODE, false>(p, al, e, smem, m0, n0);
+    else gemm256_body<EPI, ALoad, MODE, true>(p, al, e, smem, m0, n0);
 }
 
 // schedule variant of the 256^2 kernel (see MODE above); env YUME_GEMM_MODE overrides for A/B runs
@@ -626,7 +626,8 @@ int launch256(const Problem& p128, const ALoad& al, const Epilogue& e, hipStream
     p.tiles_n = (p.N + 255) / 256;
     p.group_m = g_group_m;
     dim3 grid((unsigned)(p.tiles_m * p.tiles_n)), block(NTHR256);
-    switch (g_mode256 >= 0 ? g_mode256 : mode_default) {
+    const int mode = g_mode256 >= 0 ? g_mode256 : mode_default;
+    switch (mode) {
         case 0: hipLaunchKernelGGL((gemm256_kernel<EPI, ALoad, 0>), grid, block, 0, st, p, al, e); break;
         case 1: hipLaunchKernelGGL((gemm256_kernel<EPI, ALoad, 1>), grid, block, 0, st, p, al, e); break;
         case 3: hipLaunchKernelGGL((gemm256_kernel<EPI, ALoad, 3>), grid, block, 0, st, p, al, e); break;
