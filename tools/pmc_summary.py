@@ -6,14 +6,14 @@ acc = collections.defaultdict(lambda: collections.defaultdict(list))
 dur = collections.defaultdict(list)
 for f in glob.glob(os.path.join(root, "*", "*_counter_collection.csv")):
     for r in csv.DictReader(open(f)):
-        k = r["Kernel_Name"][:90]
+        k = r["Kernel_Name"][:110]
         acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for f in glob.glob(os.path.join(root, "*", "*_kernel_trace.csv")):
     for r in csv.DictReader(open(f)):
-        dur[r["Kernel_Name"][:90]].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+        dur[r["Kernel_Name"][:110]].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
 rows = []
 for k in acc:
-    if "gemm" not in k and "attn" not in k and "adaln" not in k: continue
+    if "gemm" not in k and "attn" not in k and "adaln" not in k and "conv" not in k: continue
     d = {"kernel": k, "avg_us(profiled)": sum(dur[k]) / max(1, len(dur[k]))}
     for c, v in acc[k].items():
         d[c] = sum(v) / len(v)

@@ -4,6 +4,7 @@
 export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=${1:-$R/gpurun_out/pmc}
+case $OUT in /*) ;; *) OUT=$R/$OUT;; esac
 mkdir -p $OUT
 cd /tmp
 run() { name=$1; shift; timeout 300 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/$name -o $name -- python $R/tools/pmc_probe.py > $OUT/$name.log 2>&1; }
