@@ -64,3 +64,20 @@ def test_video_processor_matches_reference_call_shape():
     with pytest.raises(RuntimeError):
         from yume_amd import video
         video.frames_u8(v.cpu())
+
+
+def test_tiled_decode_overlap_matches_reference_outputs():
+    """golden outputs were produced by the reference's own function (oracle/make_golden_tiled.py) around the same stand-in VAE."""
+    import os
+    from oracle.make_golden_tiled import FakeVae
+    from yume_amd.video import tiled_decode_overlap, _tile_spans
+    cases = torch.load(os.path.join(ROOT, "tests", "golden", "tiled_decode.pt"))
+    assert len(cases) == 5
+    for cs in cases:
+        got = tiled_decode_overlap(FakeVae(), cs["z"], n_tiles=cs["n_tiles"], image_overlap_size=cs["image_overlap_size"],
+                                   latent_frame_zero=cs["latent_frame_zero"])
+        assert got.shape == cs["out"].shape
+        torch.testing.assert_close(got, cs["out"], rtol=1e-6, atol=1e-6)
+    # 5B 720P call shape (webapp_single_gpu.py:830): 80 latent columns, 5 bands of 16 (+2 towards each neighbour)
+    assert _tile_spans(80, 5, 2) == [(0, 18), (14, 34), (30, 50), (46, 66), (62, 80)]
+    assert _tile_spans(23, 5, 2) == [(0, 7), (3, 12), (8, 17), (13, 21), (17, 23)]

@@ -235,3 +235,20 @@ def test_vae_encode_frame_count_and_size_edge_cases(name, T, hw):
     got = vae.encode([video.to(DEV)])[0].cpu()
     assert got.shape == want.shape == (fx["cfg"]["z_dim"], 1 + (T - 1) // 4, H // s, W // s)
     assert rel_l2(got, want) <= 3e-2, rel_l2(got, want)
+
+
+def test_tiled_decode_overlap_on_the_device_vae():
+    """the webapp's width-tiled decode helper (webapp_single_gpu.py:370-551) around the real decoder: one band == the plain
+    decode; several bands reproduce the bands' own decodes where a single band has full weight, and stay close elsewhere."""
+    from yume_amd.video import tiled_decode_overlap, _tile_spans
+    fx = load_golden("vae_22")
+    vae = build_vae(fx)
+    z = fx["z"].to(DEV)                                   # [48, T, 4, 6]
+    full = vae.decode([z])[0]
+    one = tiled_decode_overlap(vae, z, n_tiles=1)
+    assert torch.equal(one, full)
+    til = tiled_decode_overlap(vae, z, n_tiles=2, image_overlap_size=16, latent_frame_zero=2)
+    assert til.shape == (3, 5, full.shape[2], full.shape[3]) and torch.isfinite(til).all()
+    (a0, a1), (b0, b1) = _tile_spans(z.shape[3], 2, 1)
+    left = vae.decode([z[:, -2:, :, a0:a1]])[0]
+    assert torch.equal(til[..., :b0 * 16], left[..., :b0 * 16])          # columns only the first band covers

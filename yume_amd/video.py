@@ -51,3 +51,54 @@ class VideoProcessor:
         if output_type == "np":
             return den.permute(0, 2, 3, 4, 1).cpu().numpy()
         raise ValueError(f"unsupported output_type {output_type!r}")
+
+
+def _tile_spans(width, n_tiles, overlap):
+    """latent column span [start, end) of each tile: near-equal widths, widened by `overlap` columns towards each neighbour."""
+    base, rem = divmod(width, n_tiles)
+    spans, at = [], 0
+    for i in range(n_tiles):
+        w = base + (1 if i < rem else 0)
+        lo = at - (overlap if i > 0 else 0)
+        hi = at + w + (overlap if i < n_tiles - 1 else 0)
+        spans.append((max(lo, 0), min(hi, width)))
+        at += w
+    return spans
+
+
+def tiled_decode_overlap(vae, latents, n_tiles=5, image_overlap_size=32, latent_frame_zero=None):
+    """Width-tiled VAE decode with blended seams: same arguments and arithmetic as the reference's memory workaround
+    (webapp_single_gpu.py:370-551, called at :830 with the 5B VAE): latents [C,T,H,W] is cut into `n_tiles` column bands, each
+    widened by image_overlap_size//16 latent columns towards its neighbours, decoded on its own (`vae.decode([band])[0]`), and
+    the bands are averaged with weights 1 for the first / last band and a linear ramp over `image_overlap_size` pixels at
+    both ends of the inner bands. `latent_frame_zero` keeps only the last that many latent frames.
+
+    On MI355X a whole 704x1280 chunk decodes in one piece (288 GB HBM), and that is what the drivers should call — a band
+    decoded without its neighbours' context differs from the full decode near the seams. This function exists so that code
+    written against the webapp's helper runs unchanged and produces what the reference's helper produces.
+    The blend is built as one weight row per band (no per-column host loop) and accumulated on the latents' device.
+    """
+    scale = 16
+    c, t, h, w = latents.shape
+    out_w = w * scale
+    spans = _tile_spans(w, n_tiles, max(1, image_overlap_size // scale))
+    result, total = None, None
+    for i, (lo, hi) in enumerate(spans):
+        band = latents[:, -latent_frame_zero:, :, lo:hi] if latent_frame_zero is not None else latents[:, :, :, lo:hi]
+        img = vae.decode([band])[0]
+        p0, p1 = lo * scale, min(hi * scale, out_w)
+        pw = p1 - p0
+        if result is None:
+            result = torch.zeros(img.shape[0], img.shape[1], img.shape[2], out_w, device=img.device, dtype=img.dtype)
+            total = torch.zeros(out_w, device=img.device, dtype=torch.float32)
+        if i == 0 or i == n_tiles - 1:
+            wrow = torch.ones(pw, device=img.device, dtype=torch.float32)
+        else:
+            j = torch.arange(pw, device=img.device, dtype=torch.float32)
+            wrow = torch.where(j < image_overlap_size, j / image_overlap_size,
+                               torch.where(j > pw - image_overlap_size, (pw - j) / image_overlap_size, torch.ones_like(j)))
+        if img.shape[3] != pw:
+            img = torch.nn.functional.interpolate(img, size=(img.shape[2], pw), mode="bilinear", align_corners=False)
+        result[..., p0:p1] += img * wrow
+        total[p0:p1] += wrow
+    return result / total.clamp(min=1e-8)
