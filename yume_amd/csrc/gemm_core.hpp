@@ -1,18 +1,25 @@
 // gemm_core.hpp — the bf16 MFMA GEMM pipeline shared by the dense GEMM (gemm_bf16.hip) and the implicit-GEMM
 // causal convolutions of the VAE (conv3d.hip):   acc[m,n] = sum_k A[m,k] * W[n,k].
 //
-// Tile 128(M) x 128(N) x 64(K), 256 threads = 4 waves in a 2x2 grid, each wave 64x64 = 4x4
-// v_mfma_f32_16x16x32_bf16 accumulators. Both operands are K-contiguous in 16-byte chunks:
-//   HBM -> LDS by LDS-DMA (global_load_lds_dwordx4, 16 B/lane), double buffered, one barrier per K tile.
-//   The LDS image is lane-linear; the bank-conflict swizzle is applied on the SOURCE address
-//   (16-byte chunk c of row r is fetched from logical chunk c ^ (r & 7)) and undone on the ds_read_b128.
-// The A operand is produced by an `ALoad` policy: a row-major matrix (PlainA) or a gather from a
-// channels-last [T,H,W,C] activation with zero padding / causal frame cache / folded 2x upsample (conv3d.hip).
-// Epilogue: accumulators are restaged through LDS per wave so every global access is a full 8/16-byte
-// vector along the contiguous dimension; bias / GELU / gate*y+residual / +addend / transposed (K-major V^T)
-// / frame-interleaved stores are fused there.
-// Workgroup order: bijective XCD remap (block b runs on XCD b%8) + grouped (8 M-tiles) traversal so the
-// blocks resident on one XCD share A row-panels and W column-panels in that XCD's L2.
+// Two kernels share the operand path (both operands K-contiguous in 16-byte chunks, HBM -> LDS by LDS-DMA
+// (global_load_lds_dwordx4, 16 B/lane); the LDS image is lane-linear, the bank-conflict swizzle is applied on the SOURCE
+// address (16-byte chunk c of row r is fetched from logical chunk c ^ (r & 7)) and undone on the ds_read_b128):
+//   gemm128_kernel  tile 128 x 128 x 64, 256 threads = 4 waves (2 x 2), each wave 64 x 64 = 4 x 4 v_mfma_f32_16x16x32_bf16
+//                   accumulators, double buffered, one barrier per K tile, two workgroups per CU. Small / ragged problems,
+//                   batched launches (gridDim.y), and the epilogues that need an LDS restage.
+//   gemm256_kernel  tile 256 x 256 x 64, 512 threads = 8 waves (2 x 4), each wave 64 x 128 as [mh][nh] quarter tiles of 4 x 2
+//                   accumulators; half-tiles are re-staged phase by phase (4 phases per K tile), the two waves sharing a SIMD
+//                   run one barrier apart (MODE 2) so one issues MFMAs while the other issues its reads. One workgroup per CU;
+//                   chosen automatically once the problem fills the chip (launch_auto). The product is computed transposed
+//                   (SWAP) for row-major outputs so a lane holds 4 consecutive columns and stores 8/16-byte vectors straight
+//                   from the accumulators; whole tiles take epilogue_rows_full (all loads of 8 accumulator groups in flight
+//                   before the first use), edge tiles the guarded per-group form.
+// The A operand is produced by an `ALoad` policy: a row-major matrix (PlainA) or a gather from a channels-last [T,H,W,C]
+// activation with zero padding / causal frame cache / folded 2x upsample (conv3d.hip).
+// Fused epilogues: bias / GELU (tanh, erf) / GEGLU / gate*y + fp32 residual / + bf16 addend / transposed (K-major V^T) /
+// frame-interleaved stores.
+// Workgroup order: bijective XCD remap (block b runs on XCD b % 8) + grouped traversal (group_m M-tiles) so the blocks
+// resident on one XCD share A row-panels and W column-panels in that XCD's L2.
 #pragma once
 #include "common.hpp"
 #include <stdlib.h>
@@ -405,6 +412,94 @@ __device__ __forceinline__ void store_col4(f32x4 v, int m, int n, const Problem&
     }
 }
 
+// Whole 256^2 tiles, row-major epilogues: a lane owns rows mlane + mh*128 + mi*16 and the 4-column groups nlane + nh*128 + ni*16.
+// Every load the epilogue needs (bias, gate rows, the fp32 residual, the conv shortcut) is issued for a batch of 8 accumulator
+// groups BEFORE the first dependent use, so a wave has 8-16 requests in flight instead of one (stores count in vmcnt on gfx9:
+// the per-group form waited for the previous store's acknowledgement 32 times per tile).
+template <int EPI>
+__device__ __forceinline__ void epilogue_rows_full(const f32x4 (&acc)[2][2][4][2], int mlane, int nlane, const Problem& p, const Epilogue& e) {
+    f32x4 b[2][2];
+#pragma unroll
+    for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+            if (e.bias) b[nh][ni] = *reinterpret_cast<const f32x4*>(e.bias + nlane + nh * 128 + ni * 16);
+            else b[nh][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    Epilogue e0 = e;
+    e0.bias = nullptr;
+    if (EPI == YUME_EPI_RESID) {
+        int64_t grow[2][4];
+#pragma unroll
+        for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+                grow[mh][mi] = (e.gate && e.row_idx) ? (int64_t)e.row_idx[mlane + mh * 128 + mi * 16] * e.gate_stride : 0;
+#pragma unroll
+        for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+            for (int nh = 0; nh < 2; ++nh) {
+                f32x4 x[4][2], g[4][2];
+                float* xo[4];
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi) {
+                    xo[mi] = reinterpret_cast<float*>(e.out) + (int64_t)(mlane + mh * 128 + mi * 16) * e.ldo + nlane + nh * 128;
+#pragma unroll
+                    for (int ni = 0; ni < 2; ++ni) x[mi][ni] = *reinterpret_cast<const f32x4*>(xo[mi] + ni * 16);
+                }
+                if (e.gate) {
+#pragma unroll
+                    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                        for (int ni = 0; ni < 2; ++ni)
+                            g[mi][ni] = *reinterpret_cast<const f32x4*>(e.gate + grow[mh][mi] + nlane + nh * 128 + ni * 16);
+                }
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < 2; ++ni) {
+                        const f32x4 v = acc[mh][nh][mi][ni] + b[nh][ni];
+                        if (e.gate) x[mi][ni] += v * g[mi][ni];
+                        else x[mi][ni] += v;
+                        *reinterpret_cast<f32x4*>(xo[mi] + ni * 16) = x[mi][ni];
+                    }
+            }
+    } else if (EPI == EPI_BF16_ADD) {
+#pragma unroll
+        for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+            for (int nh = 0; nh < 2; ++nh) {
+                u32x2 a2[4][2];
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < 2; ++ni)
+                        a2[mi][ni] = *reinterpret_cast<const u32x2*>(e.add + (int64_t)(mlane + mh * 128 + mi * 16) * e.ldadd + nlane + nh * 128 + ni * 16);
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < 2; ++ni) {
+                        f32x4 v = acc[mh][nh][mi][ni] + b[nh][ni];
+                        v[0] += bf16_to_f32((unsigned short)(a2[mi][ni][0] & 0xffffu));
+                        v[1] += bf16_to_f32((unsigned short)(a2[mi][ni][0] >> 16));
+                        v[2] += bf16_to_f32((unsigned short)(a2[mi][ni][1] & 0xffffu));
+                        v[3] += bf16_to_f32((unsigned short)(a2[mi][ni][1] >> 16));
+                        store_row4<YUME_EPI_BF16>(v, mlane + mh * 128 + mi * 16, nlane + nh * 128 + ni * 16, p, e0);
+                    }
+            }
+    } else {
+#pragma unroll
+        for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+            for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < 2; ++ni)
+                        store_row4<EPI>(acc[mh][nh][mi][ni] + b[nh][ni], mlane + mh * 128 + mi * 16, nlane + nh * 128 + ni * 16, p, e0);
+    }
+}
+
 // MODE: 0 = one barrier per phase; 1 = + s_setprio(1) around the MFMA clusters; 2 = STAGGERED: a second barrier after every
 // MFMA cluster and the wr = 1 half of the waves running one barrier behind the wr = 0 half, so that of the two waves
 // sharing a SIMD (w and w+4) one is in its MFMA cluster while the other issues its ds_reads / LDS-DMA (+ setprio);
@@ -556,6 +651,10 @@ __device__ __forceinline__ void gemm256_body(const Problem& p, ALoad& al, const 
     if (MODE >= 2 && wr == 0) __builtin_amdgcn_s_barrier();   // barrier counts of the two halves match again
     // ---- epilogue: vector stores straight from the accumulators ----
     const int l15 = lane & 15, l4 = lane >> 4;
+    if (SWAP && m0 + 256 <= p.M && n0 + 256 <= p.N) {         // whole tile (workgroup-uniform): batched loads, no guards
+        epilogue_rows_full<EPI>(acc, m0 + wr * 64 + l15, n0 + wc * 32 + 4 * l4, p, e);
+        return;
+    }
 #pragma unroll
     for (int mh = 0; mh < 2; ++mh)
 #pragma unroll

@@ -88,6 +88,9 @@ class WanModel(_Base):
                 latent_frame_zero=9, cache_sample=False, cache=None, return_cache=False, cache_list=None):
         """reference wan/modules/model.py:723-1013; returns (fp32 [C_out, F', H, W] of sample 0, cache|None)."""
         assert clip_fea is not None and y is not None
+        if len(x) != 1 or len(y) != 1:
+            raise NotImplementedError("yume_amd 14B WanModel: one sample per call (the reference samplers never batch; CFG runs "
+                                      "two calls) — got %d" % len(x))
         if enable_mask:
             raise NotImplementedError("enable_mask (MDT token masking) is a training-time path")
         # block-residual cache (:985-1000): `return_cache` records bf16 (x_out - x_in) of the blocks in cache_list (in block
