@@ -23,6 +23,7 @@
 #pragma once
 #include "common.hpp"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace gemm_core {
 
@@ -508,8 +509,22 @@ __device__ __forceinline__ void epilogue_rows_full(const f32x4 (&acc)[2][2][4][2
 // SWAP = true computes the transposed product (B fragment as the MFMA's first operand) so that a lane ends up with
 // 4 CONSECUTIVE COLUMNS n of one row m: the row-major epilogues then store 8/16-byte vectors straight from the
 // accumulators (no LDS restage). SWAP = false leaves 4 consecutive rows m per column n: the K-major V^T store.
-template <int EPI, class ALoad, int MODE, bool SWAP>
-__device__ __forceinline__ void gemm256_body(const Problem& p, ALoad& al, const Epilogue& e, char* smem, int m0, int n0) {
+typedef f32x4 Acc256[2][2][4][2];   // [mh][nh][mi][ni]: a wave's 64 x 128 part of the 256 x 256 tile
+
+__device__ __forceinline__ void acc256_zero(Acc256& acc) {
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[a][b][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+}
+
+// K tiles [kb, kb + nk) of the tile at (m0, n0) accumulated ONTO acc. kb != 0 only with PlainA (stream-K segments).
+template <class ALoad, int MODE, bool SWAP>
+__device__ __forceinline__ void gemm256_mainloop(const Problem& p, ALoad& al, char* smem, int m0, int n0, int kb, int nk, Acc256& acc) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -522,21 +537,14 @@ __device__ __forceinline__ void gemm256_body(const Problem& p, ALoad& al, const 
         const int r = rr * 64 + (tid >> 3);
         int gr = n0 + r;
         gr = gr < p.N ? gr : p.N - 1;
-        wrow[rr] = p.W + (int64_t)gr * p.ldw + (((tid & 7) ^ (r & 7)) << 3);
+        wrow[rr] = p.W + (int64_t)gr * p.ldw + (((tid & 7) ^ (r & 7)) << 3) + (int64_t)kb * BK;
     }
     al.init(m0, tid, 64);
+    if constexpr (std::is_same<ALoad, PlainA>::value) {
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) al.rowp[rr] += (int64_t)kb * BK;
+    }
 
-    f32x4 acc[2][2][4][2];   // [mh][nh][mi][ni]
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) acc[a][b][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    const int nk = p.K / BK;
     char* const s0 = smem;
     char* const s1 = smem + SLOT_BYTES;
     // half-tile offsets inside a slot
@@ -649,7 +657,14 @@ __device__ __forceinline__ void gemm256_body(const Problem& p, ALoad& al, const 
     }
 
     if (MODE >= 2 && wr == 0) __builtin_amdgcn_s_barrier();   // barrier counts of the two halves match again
-    // ---- epilogue: vector stores straight from the accumulators ----
+}
+
+// ---- epilogue: vector stores straight from the accumulators ----
+template <int EPI, bool SWAP>
+__device__ __forceinline__ void gemm256_epilogue(const Acc256& acc, const Problem& p, const Epilogue& e, int m0, int n0) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
     const int l15 = lane & 15, l4 = lane >> 4;
     if (SWAP && m0 + 256 <= p.M && n0 + 256 <= p.N) {         // whole tile (workgroup-uniform): batched loads, no guards
         epilogue_rows_full<EPI>(acc, m0 + wr * 64 + l15, n0 + wc * 32 + 4 * l4, p, e);
@@ -678,28 +693,41 @@ __device__ __forceinline__ void gemm256_body(const Problem& p, ALoad& al, const 
                 }
 }
 
+template <int EPI, class ALoad, int MODE, bool SWAP>
+__device__ __forceinline__ void gemm256_body(const Problem& p, ALoad& al, const Epilogue& e, char* smem, int m0, int n0) {
+    Acc256 acc;
+    acc256_zero(acc);
+    gemm256_mainloop<ALoad, MODE, SWAP>(p, al, smem, m0, n0, 0, p.K / BK, acc);
+    gemm256_epilogue<EPI, SWAP>(acc, p, e, m0, n0);
+}
+
 // (built, parity-green and measured slower, see profiles/r2_rejected_experiments.md: a v_mfma_f32_32x32x16_bf16 main loop (r1, -13 %); the
 // fragment reads software-pipelined one phase ahead with ping-pong register sets (-1...-15 %); a one-wave-per-SIMD kernel with all
 // 256 AGPRs as accumulators, K tiles of 32 and 0.5 ds_read per MFMA (-13...-20 %))
+
+// position `wg` of the grouped tile order (group_m M-tiles x all N-tiles per group, M fastest) -> tile origin
+__device__ __forceinline__ void tile_origin(const Problem& p, int wg, int& m0, int& n0) {
+    const int width = p.group_m * p.tiles_n;
+    const int group = wg / width;
+    const int first_m = group * p.group_m;
+    const int gsz = min(p.tiles_m - first_m, p.group_m);
+    m0 = (first_m + (wg % width) % gsz) * 256;
+    n0 = ((wg % width) / gsz) * 256;
+}
+// XCD x walks its own contiguous chunk [start, start + count) of that order (block b runs on XCD b % 8)
+__device__ __forceinline__ void xcd_chunk(int nwg, int xcd, int& start, int& count) {
+    const int q = nwg >> 3, r = nwg & 7;
+    start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    count = q + (xcd < r ? 1 : 0);
+}
 
 template <int EPI, class ALoad, int MODE>
 __global__ __launch_bounds__(NTHR256, 2) void gemm256_kernel(Problem p, ALoad al, Epilogue e) {
     __shared__ __attribute__((aligned(16))) char smem[LDS256_BYTES];
     // ---- workgroup -> tile (XCD-aware, grouped) ----
-    const int nwg = p.tiles_m * p.tiles_n;
-    int wg;
-    {
-        const int bid = blockIdx.x;
-        const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
-        wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-    }
-    const int width = p.group_m * p.tiles_n;
-    const int group = wg / width;
-    const int first_m = group * p.group_m;
-    const int gsz = min(p.tiles_m - first_m, p.group_m);
-    const int tm = first_m + (wg % width) % gsz;
-    const int tn = (wg % width) / gsz;
-    const int m0 = tm * 256, n0 = tn * 256;
+    int start, count, m0, n0;
+    xcd_chunk(p.tiles_m * p.tiles_n, blockIdx.x & 7, start, count);
+    tile_origin(p, start + (blockIdx.x >> 3), m0, n0);
     if (EPI == YUME_EPI_BF16_SPLITT && n0 >= e.n_split) gemm256_body<EPI, ALoad, MODE, false>(p, al, e, smem, m0, n0);
     else gemm256_body<EPI, ALoad, MODE, true>(p, al, e, smem, m0, n0);
 }
