@@ -66,12 +66,14 @@ __device__ __forceinline__ float wave_max(float v) {
 
 // tanh-approximated GELU exactly as torch.nn.GELU(approximate='tanh'):
 //   0.5*x*(1+tanh(sqrt(2/pi)*(x+0.044715 x^3)))
+// With tanh(u) = 1 - 2/(exp(2u)+1) the expression is x / (1 + exp(-2u)) (no cancellation in either tail): one v_exp_f32 (exp2 of the
+// pre-scaled argument), one v_rcp_f32 (1 ulp, no IEEE division sequence) and five full-rate ops per element — the GEMM epilogue
+// evaluates it 128 times per lane with the matrix pipe idle. Saturates cleanly: exp2 -> 0 gives x, exp2 -> inf gives x * 0.
 __device__ __forceinline__ float gelu_tanh(float x) {
-    const float k0 = 0.7978845608028654f, k1 = 0.044715f;
-    float u = k0 * (x + k1 * x * x * x);
-    // tanh(u) = 1 - 2/(exp(2u)+1); saturates cleanly for |u| large
-    float e = __expf(2.0f * u);
-    float t = 1.0f - 2.0f / (e + 1.0f);
-    return 0.5f * x * (1.0f + t);
+    const float c0 = -2.0f * 0.7978845608028654f * 1.4426950408889634f;   // -2 * sqrt(2/pi) * log2(e)
+    const float c1 = c0 * 0.044715f;
+    const float x2 = x * x;
+    const float e = __builtin_amdgcn_exp2f(x * (c1 * x2 + c0));            // exp(-2u)
+    return x * __builtin_amdgcn_rcpf(e + 1.0f);
 }
 __device__ __forceinline__ float silu(float x) { return x / (1.0f + __expf(-x)); }
