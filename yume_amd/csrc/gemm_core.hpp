@@ -53,6 +53,7 @@ struct Problem {
     int tiles_m, tiles_n;
     int group_m;   // 256^2 kernel: M-tiles per traversal group (L2 reuse knob)
     int64_t bsW, bsO;   // batched launch (gridDim.y > 1, 128^2 kernel): W stride in elements, out stride in BYTES per batch index
+    int epi_direct;     // A/B switch (env YUME_GEMM_EPI_DIRECT=1): 256^2 kernel stores bf16 tiles straight from the accumulators
 };
 
 typedef __attribute__((address_space(3))) void lds_void;
@@ -660,12 +661,71 @@ __device__ __forceinline__ void gemm256_mainloop(const Problem& p, ALoad& al, ch
 }
 
 // ---- epilogue: vector stores straight from the accumulators ----
-template <int EPI, bool SWAP>
-__device__ __forceinline__ void gemm256_epilogue(const Acc256& acc, const Problem& p, const Epilogue& e, int m0, int n0) {
+// bf16 row-major outputs, tiles with all 256 columns inside N: the tile is restaged through the (now free) operand slots as a
+// [256][256] bf16 image and leaves as whole 512-byte rows, 1 KiB per wave-instruction. Straight from the accumulators a lane owns
+// 4 columns of one row, i.e. a store instruction writes sixteen 32-byte pieces of sixteen rows (measured: 5 % of a K = 3072 GEMM).
+// 16-byte chunk c of row r sits at chunk c ^ (r & 31): the ds_write_b64 of 16 rows x one chunk column is 2-way conflicted (within the
+// instruction's own transfer time), the ds_read_b128 of 32 chunks of one row is conflict-free.
+template <int EPI>
+__device__ __forceinline__ void epilogue_rows_lds(const Acc256& acc, char* smem, int m0, int n0, const Problem& p, const Epilogue& e) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wr = wave >> 2, wc = wave & 3;
     const int l15 = lane & 15, l4 = lane >> 4;
+    f32x4 b[2][2];
+#pragma unroll
+    for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+            if (e.bias) b[nh][ni] = *reinterpret_cast<const f32x4*>(e.bias + n0 + nh * 128 + wc * 32 + ni * 16 + 4 * l4);
+            else b[nh][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    __syncthreads();                                  // every wave is done with the operand slots
+#pragma unroll
+    for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+        for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) {
+                    f32x4 v = acc[mh][nh][mi][ni] + b[nh][ni];
+                    if (EPI == YUME_EPI_BF16_GELU) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) v[q] = gelu_tanh(v[q]);
+                    }
+                    if (EPI == YUME_EPI_BF16_GELU_ERF) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) v[q] = 0.5f * v[q] * (1.0f + erff(v[q] * 0.7071067811865476f));
+                    }
+                    const int r = mh * 128 + wr * 64 + mi * 16 + l15;
+                    const int c = nh * 128 + wc * 32 + ni * 16 + 4 * l4;          // bf16 column inside the tile
+                    u32x2 o;
+                    o[0] = pack_bf16x2(v[0], v[1]);
+                    o[1] = pack_bf16x2(v[2], v[3]);
+                    *reinterpret_cast<u32x2*>(smem + r * 512 + ((((c >> 3) ^ r) & 31) << 4) + ((c >> 2) & 1) * 8) = o;
+                }
+    __syncthreads();
+    unsigned short* out = reinterpret_cast<unsigned short*>(e.out) + n0 + (lane & 31) * 8;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int r = wave * 32 + i * 2 + (lane >> 5);
+        const u32x4 d = *reinterpret_cast<const u32x4*>(smem + r * 512 + ((((lane & 31) ^ r) & 31) << 4));
+        if (m0 + r < p.M) *reinterpret_cast<u32x4*>(out + (int64_t)(m0 + r) * e.ldo) = d;
+    }
+}
+
+template <int EPI, bool SWAP>
+__device__ __forceinline__ void gemm256_epilogue(const Acc256& acc, const Problem& p, const Epilogue& e, int m0, int n0, char* smem) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    if (SWAP && !p.epi_direct && n0 + 256 <= p.N && (e.ldo % 8) == 0 &&
+        (EPI == YUME_EPI_BF16 || EPI == YUME_EPI_BF16_GELU || EPI == YUME_EPI_BF16_GELU_ERF || EPI == YUME_EPI_BF16_SPLITT)) {
+        epilogue_rows_lds<EPI>(acc, smem, m0, n0, p, e);      // (workgroup-uniform condition)
+        return;
+    }
     if (SWAP && m0 + 256 <= p.M && n0 + 256 <= p.N) {         // whole tile (workgroup-uniform): batched loads, no guards
         epilogue_rows_full<EPI>(acc, m0 + wr * 64 + l15, n0 + wc * 32 + 4 * l4, p, e);
         return;
@@ -698,7 +758,7 @@ __device__ __forceinline__ void gemm256_body(const Problem& p, ALoad& al, const 
     Acc256 acc;
     acc256_zero(acc);
     gemm256_mainloop<ALoad, MODE, SWAP>(p, al, smem, m0, n0, 0, p.K / BK, acc);
-    gemm256_epilogue<EPI, SWAP>(acc, p, e, m0, n0);
+    gemm256_epilogue<EPI, SWAP>(acc, p, e, m0, n0, smem);
 }
 
 // (built, parity-green and measured slower, see profiles/r2_rejected_experiments.md: a v_mfma_f32_32x32x16_bf16 main loop (r1, -13 %); the
@@ -752,6 +812,7 @@ int launch256(const Problem& p128, const ALoad& al, const Epilogue& e, hipStream
     p.tiles_m = (p.M + 255) / 256;
     p.tiles_n = (p.N + 255) / 256;
     p.group_m = g_group_m;
+    { static const int d = [] { const char* v = getenv("YUME_GEMM_EPI_DIRECT"); return v ? atoi(v) : 0; }(); p.epi_direct = d; }
     dim3 grid((unsigned)(p.tiles_m * p.tiles_n)), block(NTHR256);
     const int mode = g_mode256 >= 0 ? g_mode256 : mode_default;
     switch (mode) {
