@@ -1,3 +1,9 @@
 export TMPDIR=/tmp
-for d in 0 1 0 1; do echo DIRECT $d; YUME_GEMM_EPI_DIRECT=$d timeout 200 tools/gemm_check --timing 2>&1 | grep "big/256" | grep "epi=0\|epi=1\|epi=4" | cut -c1-52,95-220; done
-for d in 0 1; do echo VAE DIRECT $d; YUME_GEMM_EPI_DIRECT=$d python tools/vae_probe.py 2>&1 | grep "decode\|encode" | tail -2; done
+python bench.py 2>&1 | grep -v amdgpu.ids | tail -1 > gpurun_out/r2_bench_v3.log; python - <<'PY'
+import json
+d=json.loads(open('gpurun_out/r2_bench_v3.log').read())
+print(d['value'], d['ms_per_step'], d.get('cached_context_ms_per_step'), d['vae_decode']['latents_per_s'])
+for r in [d['roofline']]+d['roofline_all']:
+    print(r['group'], round(r.get('launch_ms',0),4), round(r.get('ms_per_step',0),2), round(r.get('achieved',0),1), r.get('traffic'))
+print(d.get('parity'))
+PY
