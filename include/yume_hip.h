@@ -36,7 +36,7 @@ extern "C" {
 /* ---- library info ------------------------------------------------------------------- */
 const char* yume_last_error(void);
 /* ABI version of this header; bumped on any signature change (yume_amd/_lib.py refuses a library that reports another one). */
-#define YUME_ABI_VERSION 3
+#define YUME_ABI_VERSION 4
 int yume_abi_version(void);
 /* name of the gfx target the kernels were compiled for ("gfx950"). */
 const char* yume_target_arch(void);
@@ -132,7 +132,15 @@ int yume_rmsnorm_rows_periodic(void* buf, int64_t ld, int64_t T, int64_t C, cons
  * variant: 0 = automatic (Lk >= 1536 and Lq >= 256: the one-wave-per-SIMD kernel, 256 queries per workgroup; otherwise
  *    the 4-wave LDS-DMA kernel), 1 = 4-wave register-staged kernel, 2 = 4-wave LDS-DMA kernel, 4 = 8-wave ping-pong
  *    kernel, 7 = one-wave-per-SIMD kernel (attn_fwd7.hip). All compute the same function (tests compare them).
+ *    | YUME_ATTN_Q_PRESCALED: Q already carries scale * log2(e) — the caller folded that factor into the producer of Q before
+ *    its one bf16 rounding (the DiT engine multiplies it into the RMSNorm weight of q, so yume_rmsnorm_rope writes it) — and
+ *    `scale` is ignored:  O = sum_j 2^<Q,K_j> V_j / sum_j 2^<Q,K_j>.  The scores then leave the matrix pipe as the exponents
+ *    themselves; the one-wave-per-SIMD kernel drops the per-score shift and keeps NO running base (floating point is
+ *    scale-invariant: exp2(s - m) and exp2(s) carry the same relative error, m cancels in O / l). Its guard is a range check
+ *    of every row sum and output at the end of a workgroup; a workgroup that fails it (scores beyond about +-100 in the log2
+ *    domain) is rerun in the same launch on the kernel's rescaling path, so the result is defined for every input.
  */
+#define YUME_ATTN_Q_PRESCALED 0x100
 int yume_attn_fwd(const void* Q, int64_t ldq, const void* K, int64_t ldk, const void* Vt, int64_t ldvt,
                   void* O, int64_t ldo, int64_t Lq, int64_t Lk, int64_t H, float scale,
                   int accumulate, int variant, void* stream);

@@ -164,14 +164,14 @@ def attn_ref(q, k, v, scale):
     return (a @ vd).transpose(0, 1)                                     # [Lq, H, D]
 
 
-def run_attn(q, k, v, scale=None, accumulate=None, variant=0):
+def run_attn(q, k, v, scale=None, accumulate=None, variant=0, q_prescaled=False):
     Lq, H, D = q.shape
     Lk = k.shape[0]
     vt = torch.empty(H * D, (Lk + 7) // 8 * 8, dtype=torch.bfloat16, device=DEV).fill_(float("nan"))
     ops.transpose_bf16(v.reshape(Lk, H * D).to(DEV), vt)
     out = torch.empty(Lq, H * D, dtype=torch.bfloat16, device=DEV) if accumulate is None else accumulate
     ops.attn_fwd(q.reshape(Lq, H * D).to(DEV), k.reshape(Lk, H * D).to(DEV), vt, out, Lq, Lk, H, scale=scale,
-                 accumulate=accumulate is not None, variant=variant)
+                 accumulate=accumulate is not None, variant=variant, q_prescaled=q_prescaled)
     return out.cpu().view(Lq, H, D)
 
 
@@ -217,6 +217,49 @@ def test_attention_accumulate_and_transposed_operand(variant):
     got = run_attn(q, k, v2, variant=variant)
     want = attn_ref(q, k, v2, 1 / math.sqrt(128))
     assert (got.double() - want).abs().max() <= 2e-2 * want.abs().max()
+
+
+def _prescale(q, scale=1 / math.sqrt(128)):
+    """what the DiT engine hands the attention kernel: q * scale * log2(e), rounded to bf16 ONCE (there: inside yume_rmsnorm_rope)"""
+    return (q.double() * (scale * math.log2(math.e))).to(torch.bfloat16)
+
+
+@pytest.mark.parametrize("Lq,Lk,H", [(1, 1, 2), (300, 300, 3), (517, 257, 2), (256, 1536, 1), (300, 1600, 2), (700, 2100, 8), (512, 4096, 3), (1100, 1984, 8), (2048, 2048, 8)])
+@pytest.mark.parametrize("variant", [0, 2, 7])
+def test_attention_prescaled_q(Lq, Lk, H, variant):
+    """YUME_ATTN_Q_PRESCALED: O = sum_j 2^(q'.k_j) v_j / sum_j 2^(q'.k_j) = softmax(ln 2 * q' k^T) v — the base-free pieces of the
+    one-wave-per-SIMD kernel (variants 0 at Lk >= 1536, 7) and the same flag through the other kernels (scale_log2 = 1)."""
+    q, k, v = (rnd(L, H, 128, seed=s, dtype=torch.bfloat16) for L, s in ((Lq, 1), (Lk, 2), (Lk, 3)))
+    qp = _prescale(q)
+    want = attn_ref(qp, k, v, math.log(2.0))
+    got = run_attn(qp, k, v, variant=variant, q_prescaled=True)
+    assert torch.isfinite(got).all()
+    assert (got.double() - want).abs().max() <= 1.5e-2 * max(want.abs().max().item(), 1e-3)
+    assert rel_l2(got, want) < 6e-3
+    # and it is the function the unscaled call computes, up to the one extra rounding of q this test (not the engine) pays
+    plain = run_attn(q, k, v, variant=variant)
+    assert rel_l2(got, plain) < 1.2e-2
+
+
+@pytest.mark.parametrize("variant", [0, 7])
+@pytest.mark.parametrize("Lq,Lk,H", [(300, 1600, 2), (700, 2100, 8), (256, 64, 1), (8500, 2100, 8)])
+def test_attention_prescaled_q_out_of_range_rows_take_the_robust_pieces(Lq, Lk, H, variant):
+    """scores far outside what exp2 can hold without a base: one query with a score of several hundred (its exponential is inf), one whose
+    scores all sit near -400 (every exponential flushes to 0), one at +100 (fine without a base). The workgroups holding the first two
+    fail the range check at their end and are rerun, inside the launch, on the rescaling pieces; all rows match the exact softmax."""
+    q, k, v = (rnd(L, H, 128, seed=s, dtype=torch.bfloat16) for L, s in ((Lq, 11), (Lk, 12), (Lk, 13)))
+    q, k = q.float(), k.float()
+    k[:, :, 0] = 8.0
+    q[Lq - 2, :, 0] = -400.0
+    k[5] = q[3] * 40
+    k[Lk - 9] = q[Lq // 2] * 6
+    q, k = q.to(torch.bfloat16), k.to(torch.bfloat16)
+    qp = _prescale(q)
+    want = attn_ref(qp, k, v, math.log(2.0))
+    got = run_attn(qp, k, v, variant=variant, q_prescaled=True)
+    assert torch.isfinite(got).all()
+    assert (got.double() - want).abs().max() <= 2e-2 * want.abs().max()
+    assert rel_l2(got, want) < 6e-3
 
 
 def test_attention_auto_splits_query_range_between_kernels():

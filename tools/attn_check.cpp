@@ -1,6 +1,7 @@
 // attn_check — standalone (no torch) correctness + timing harness for yume_attn_fwd variants.
 //   build:  hipcc -O2 --offload-arch=gfx950 tools/attn_check.cpp -o tools/attn_check -Lyume_amd/lib -lyume_hip -Wl,-rpath,'$ORIGIN/../yume_amd/lib'
-//   run:    tools/attn_check [variants...]        (default variants: 7 4 2 0)
+//   run:    tools/attn_check [variants...]        (default variants: 7 263 256 4 2 0; v + 256 = v | YUME_ATTN_Q_PRESCALED: the harness
+//           hands the kernel q' = bf16(q * scale * log2 e) and the references take exp2(q' . k))
 // Small shapes are checked against an fp64 exact-softmax reference computed on the host (test infrastructure, like oracle/);
 // large shapes are checked against variant 2 (itself checked on the small shapes) and timed with HIP events.
 #include <hip/hip_runtime.h>
@@ -42,11 +43,14 @@ static float rnd() {   // ~N(0,1): sum of 4 uniforms
 
 struct Prob {
     int64_t Lq, Lk, H, ldq, ldk, ldvt, ldo;
-    std::vector<uint16_t> q, k, vt, o0;
-    uint16_t *dq, *dk, *dvt, *d_o;
+    std::vector<uint16_t> q, qpre, k, vt, o0;
+    uint16_t *dq, *dqpre, *dk, *dvt, *d_o;
     void* ws; int64_t wsb;
 };
 
+static const double kScale = 0.08838834764831845, kLog2e = 1.4426950408889634;
+// spike: 0 none, 1 one key far above the rest late in the sequence (rescale / redo path), 2 scores far outside +-100 in the log2 domain for
+// some queries (huge positive and huge negative rows: the base-free pieces must hand the workgroup to the robust ones)
 static void make(Prob& p, int64_t Lq, int64_t Lk, int64_t H, int spike) {
     p.Lq = Lq; p.Lk = Lk; p.H = H;
     p.ldq = H * 128; p.ldk = H * 128; p.ldo = H * 128;
@@ -67,6 +71,20 @@ static void make(Prob& p, int64_t Lq, int64_t Lk, int64_t H, int spike) {
                 p.k[key * p.ldk + h * 128 + d] = f2bf(qv * 6.0f);
             }
     }
+    if (spike == 2) {
+        // query row 3: key 5 = 40 x that query -> a score of several hundred (log2 domain); query row Lq - 2: every key carries a constant
+        // +8 in feature 0 (a uniform shift for the other queries) and this query -400 there -> every one of its scores is about -400
+        const int64_t q1 = 3 < Lq ? 3 : 0, q2 = Lq - 2 >= 0 ? Lq - 2 : 0, k1 = 5 < Lk ? 5 : 0;
+        for (int64_t h = 0; h < H; ++h) {
+            for (int64_t j = 0; j < Lk; ++j) p.k[j * p.ldk + h * 128] = f2bf(8.0f);
+            if (q2 != q1) p.q[q2 * p.ldq + h * 128] = f2bf(-400.0f);
+            for (int d = 0; d < 128; ++d) p.k[k1 * p.ldk + h * 128 + d] = f2bf(bf2f(p.q[q1 * p.ldq + h * 128 + d]) * 40.0f);
+        }
+    }
+    p.qpre.resize(p.q.size());
+    for (size_t i = 0; i < p.q.size(); ++i) p.qpre[i] = f2bf((float)((double)bf2f(p.q[i]) * kScale * kLog2e));
+    HC(hipMalloc(&p.dqpre, p.q.size() * 2));
+    HC(hipMemcpy(p.dqpre, p.qpre.data(), p.q.size() * 2, hipMemcpyHostToDevice));
     HC(hipMalloc(&p.dq, p.q.size() * 2)); HC(hipMalloc(&p.dk, p.k.size() * 2)); HC(hipMalloc(&p.dvt, p.vt.size() * 2)); HC(hipMalloc(&p.d_o, p.o0.size() * 2));
     HC(hipMemcpy(p.dq, p.q.data(), p.q.size() * 2, hipMemcpyHostToDevice));
     HC(hipMemcpy(p.dk, p.k.data(), p.k.size() * 2, hipMemcpyHostToDevice));
@@ -75,11 +93,11 @@ static void make(Prob& p, int64_t Lq, int64_t Lk, int64_t H, int spike) {
     p.ws = nullptr;
     if (p.wsb) HC(hipMalloc(&p.ws, p.wsb));
 }
-static void drop(Prob& p) { hipFree(p.dq); hipFree(p.dk); hipFree(p.dvt); hipFree(p.d_o); if (p.ws) hipFree(p.ws); }
+static void drop(Prob& p) { hipFree(p.dqpre); hipFree(p.dq); hipFree(p.dk); hipFree(p.dvt); hipFree(p.d_o); if (p.ws) hipFree(p.ws); }
 
 static int run(Prob& p, int variant, int accumulate, std::vector<uint16_t>& out) {
     HC(hipMemcpy(p.d_o, p.o0.data(), p.o0.size() * 2, hipMemcpyHostToDevice));
-    int rc = yume_attn_fwd_ws(p.dq, p.ldq, p.dk, p.ldk, p.dvt, p.ldvt, p.d_o, p.ldo, p.Lq, p.Lk, p.H, 0.08838834764831845f, accumulate, variant,
+    int rc = yume_attn_fwd_ws((variant & 256) ? p.dqpre : p.dq, p.ldq, p.dk, p.ldk, p.dvt, p.ldvt, p.d_o, p.ldo, p.Lq, p.Lk, p.H, 0.08838834764831845f, accumulate, variant,
                               p.ws, p.wsb, nullptr);
     if (rc) { printf("  variant %d: rc=%d %s\n", variant, rc, yume_last_error()); return rc; }
     hipError_t e = hipDeviceSynchronize();
@@ -89,7 +107,9 @@ static int run(Prob& p, int variant, int accumulate, std::vector<uint16_t>& out)
     return 0;
 }
 
-static void reference(const Prob& p, int accumulate, std::vector<float>& ref) {
+static void reference(const Prob& p, int accumulate, std::vector<float>& ref, bool pre = false) {
+    const std::vector<uint16_t>& Q = pre ? p.qpre : p.q;
+    const double sc = pre ? 0.6931471805599453 : kScale;      // exp2(q' . k) = exp(ln 2 * q' . k)
     ref.assign(p.Lq * p.ldo, 0.f);
     std::vector<double> s(p.Lk);
     for (int64_t h = 0; h < p.H; ++h)
@@ -97,8 +117,8 @@ static void reference(const Prob& p, int accumulate, std::vector<float>& ref) {
             double mx = -1e300;
             for (int64_t j = 0; j < p.Lk; ++j) {
                 double a = 0;
-                for (int d = 0; d < 128; ++d) a += (double)bf2f(p.q[i * p.ldq + h * 128 + d]) * bf2f(p.k[j * p.ldk + h * 128 + d]);
-                s[j] = a * 0.08838834764831845;
+                for (int d = 0; d < 128; ++d) a += (double)bf2f(Q[i * p.ldq + h * 128 + d]) * bf2f(p.k[j * p.ldk + h * 128 + d]);
+                s[j] = a * sc;
                 mx = s[j] > mx ? s[j] : mx;
             }
             double l = 0;
@@ -138,10 +158,12 @@ int main(int argc, char** argv) {
     std::vector<int> variants;
     const char* lib = "yume_amd/lib/libyume_hip.so";
     bool timing_only = false;
+    int big_spike = 1;
     int one[3] = {0, 0, 0};
     for (int i = 1; i < argc; ++i) {
         if (!strcmp(argv[i], "--lib")) lib = argv[++i];
         else if (!strcmp(argv[i], "--timing")) timing_only = true;
+        else if (!strcmp(argv[i], "--nospike")) big_spike = 0;
         else if (!strcmp(argv[i], "--one")) { one[0] = atoi(argv[i + 1]); one[1] = atoi(argv[i + 2]); one[2] = atoi(argv[i + 3]); i += 3; timing_only = true; }
         else variants.push_back(atoi(argv[i]));
     }
@@ -149,21 +171,25 @@ int main(int argc, char** argv) {
     if (!hnd) { printf("dlopen %s: %s\n", lib, dlerror()); return 2; }
     p_attn = (attn_fn)dlsym(hnd, "yume_attn_fwd_ws"); p_ws = (ws_fn)dlsym(hnd, "yume_attn_workspace_bytes"); p_err = (err_fn)dlsym(hnd, "yume_last_error");
     printf("library %s\n", lib);
-    if (variants.empty()) variants = {7, 4, 2, 0};
+    if (variants.empty()) variants = {7, 263, 256, 4, 2, 0};
     int fails = 0;
     const int small[][4] = {{256, 64, 1, 0}, {64, 40, 1, 0}, {1, 1, 1, 0}, {300, 200, 2, 0}, {273, 323, 3, 0}, {256, 256, 1, 0}, {256, 320, 1, 0},
                             {513, 640, 9, 0}, {700, 1000, 8, 1}, {256, 577, 2, 1}, {260, 448, 1, 0}, {512, 512, 3, 1}, {384, 1999, 2, 1},
-                            {700, 2100, 8, 1}, {1000, 3333, 16, 1}, {300, 1536, 1, 0}};
+                            {700, 2100, 8, 1}, {1000, 3333, 16, 1}, {300, 1536, 1, 0}, {300, 1600, 2, 2}, {700, 2100, 8, 2}, {512, 4096, 3, 2},
+                            {256, 64, 1, 2}, {1100, 1984, 8, 0}};
     for (auto& sh : small) {
         if (timing_only) break;
         for (int acc = 0; acc < 2; ++acc) {
             Prob p; make(p, sh[0], sh[1], sh[2], sh[3]);
-            std::vector<float> ref; reference(p, acc, ref);
+            std::vector<float> ref, refpre; reference(p, acc, ref);
+            bool anypre = false;
+            for (int v : variants) anypre |= (v & 256) != 0;
+            if (anypre) reference(p, acc, refpre, true);
             for (int v : variants) {
                 if ((v == 4) && (sh[0] < 1)) continue;
                 std::vector<uint16_t> out;
                 if (run(p, v, acc, out)) { ++fails; continue; }
-                int nan; double md = maxdiff(out, ref, &nan);
+                int nan; double md = maxdiff(out, (v & 256) ? refpre : ref, &nan);
                 const bool ok = nan == 0 && md < (acc ? 6e-2 : 4e-2);
                 printf("small Lq=%d Lk=%d H=%d spike=%d acc=%d variant=%d  maxabs=%.3e nan=%d %s\n", sh[0], sh[1], sh[2], sh[3], acc, v, md, nan, ok ? "ok" : "FAIL");
                 if (!ok) ++fails;
@@ -184,18 +210,20 @@ int main(int argc, char** argv) {
     int nbig = 0;
     for (auto& sh : big) {
         if (timing_only && nbig++ >= 3) break;
-        Prob p; make(p, sh[0], sh[1], sh[2], 1);
-        std::vector<uint16_t> base;
+        Prob p; make(p, sh[0], sh[1], sh[2], big_spike);
+        std::vector<uint16_t> base, basepre;
         if (run(p, 2, 0, base)) { ++fails; drop(p); continue; }
+        if (run(p, 2 | 256, 0, basepre)) { ++fails; drop(p); continue; }
         for (int v : variants) {
             std::vector<uint16_t> out;
             if (run(p, v, 0, out)) { ++fails; continue; }
-            int nan; double md = maxdiff2(out, base, &nan);
+            int nan; double md = maxdiff2(out, (v & 256) ? basepre : base, &nan);
             hipEvent_t e0, e1; HC(hipEventCreate(&e0)); HC(hipEventCreate(&e1));
             const int it = sh[0] > 20000 ? 3 : 10;
-            for (int i = 0; i < 2; ++i) yume_attn_fwd_ws(p.dq, p.ldq, p.dk, p.ldk, p.dvt, p.ldvt, p.d_o, p.ldo, p.Lq, p.Lk, p.H, 0.0883883f, 0, v, p.ws, p.wsb, nullptr);
+            const uint16_t* qd = (v & 256) ? p.dqpre : p.dq;
+            for (int i = 0; i < 2; ++i) yume_attn_fwd_ws(qd, p.ldq, p.dk, p.ldk, p.dvt, p.ldvt, p.d_o, p.ldo, p.Lq, p.Lk, p.H, 0.0883883f, 0, v, p.ws, p.wsb, nullptr);
             HC(hipEventRecord(e0, nullptr));
-            for (int i = 0; i < it; ++i) yume_attn_fwd_ws(p.dq, p.ldq, p.dk, p.ldk, p.dvt, p.ldvt, p.d_o, p.ldo, p.Lq, p.Lk, p.H, 0.0883883f, 0, v, p.ws, p.wsb, nullptr);
+            for (int i = 0; i < it; ++i) yume_attn_fwd_ws(qd, p.ldq, p.dk, p.ldk, p.dvt, p.ldvt, p.d_o, p.ldo, p.Lq, p.Lk, p.H, 0.0883883f, 0, v, p.ws, p.wsb, nullptr);
             HC(hipEventRecord(e1, nullptr)); HC(hipEventSynchronize(e1));
             float ms; HC(hipEventElapsedTime(&ms, e0, e1)); ms /= it;
             const double tf = 4.0 * sh[0] * sh[1] * 128.0 * sh[2] / (ms * 1e-3) / 1e12;

@@ -49,7 +49,7 @@ SIGNATURES = {
 _RES = {"yume_last_error": c_char_p, "yume_target_arch": c_char_p, "yume_gemm_splitk_workspace_bytes": c_int64, "yume_attn_workspace_bytes": c_int64}
 
 _lib = None
-ABI_VERSION = 3          # must equal YUME_ABI_VERSION in include/yume_hip.h; bumped whenever an argument list changes
+ABI_VERSION = 4          # must equal YUME_ABI_VERSION in include/yume_hip.h; bumped whenever an argument list changes
 
 
 def load():

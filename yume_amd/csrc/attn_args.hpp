@@ -9,7 +9,8 @@ struct AttnArgs {
     const unsigned short* Vt; int64_t ldvt;
     unsigned short* O; int64_t ldo;
     int Lq, Lk, H;
-    float scale_log2;  // softmax scale * log2(e)
+    float scale_log2;  // softmax scale * log2(e); exactly 1 when q_prescaled
+    int q_prescaled;   // Q already carries softmax scale * log2(e) (YUME_ATTN_Q_PRESCALED): the scores are the exponents
     int accumulate;
     int nqb;           // query blocks per head (of the rows [q_lo, Lq) this launch covers)
     int q_lo;          // first query row of this launch

@@ -1033,7 +1033,12 @@ extern "C" int yume_attn_fwd_ws(const void* Q, int64_t ldq, const void* K, int64
     a.Vt = (const unsigned short*)Vt; a.ldvt = ldvt;
     a.O = (unsigned short*)O; a.ldo = ldo;
     a.Lq = (int)Lq; a.Lk = (int)Lk; a.H = (int)H;
-    a.scale_log2 = scale * 1.4426950408889634f;
+    // YUME_ATTN_Q_PRESCALED: Q already carries scale * log2(e) (the caller folded it into the producer of Q before its bf16 rounding): the
+    // scores are the exponents. `scale` is ignored; every kernel sees scale_log2 = 1, the one-wave-per-SIMD kernel runs its base-free pieces.
+    const int q_pre = (variant & YUME_ATTN_Q_PRESCALED) != 0;
+    variant &= ~YUME_ATTN_Q_PRESCALED;
+    a.q_prescaled = q_pre;
+    a.scale_log2 = q_pre ? 1.0f : scale * 1.4426950408889634f;
     a.accumulate = accumulate;
     a.q_lo = 0;
     a.nqb = 0;

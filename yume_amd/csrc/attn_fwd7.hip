@@ -40,7 +40,10 @@ constexpr int NS = 4;                     // slots per operand
 constexpr int VB = NS * SLOT;             // V^T slots start here
 constexpr int LDS7 = 2 * NS * SLOT;       // 128 KiB
 constexpr int QB7 = 256;                  // queries per workgroup
-constexpr int RD = 4;                     // V^T fragment ring depth: a fragment is read RD MFMA gaps before its MFMA (8 measured the same)
+#ifndef A7_RD
+#define A7_RD 4
+#endif
+constexpr int RD = A7_RD;                     // V^T fragment ring depth: a fragment is read RD MFMA gaps before its MFMA (8 measured the same)
 constexpr float NEG_BIG = -1.0e30f;
 constexpr float OVERFLOW_LOG2 = 13.0f;       // deferred rescale: exponentials stay below 2^13 against the running base
 constexpr float OVERFLOW_SUM = 8192.0f;       // = 2^13: a larger partial row sum (32 exponentials) proves one of them exceeded 2^8
@@ -71,6 +74,17 @@ constexpr int OA = 0, OB = 64, QA = 128, QB = 160, KC0 = 192;
 // the same S MFMAs with the K fragment taken from the cache a[k:k+3]
 #define MFMA_S0_KC(d, k, q, y) asm volatile("v_mfma_f32_32x32x16_bf16 %0, a[%c1:%c2], a[%c3:%c4], 0" : "=&v"(d) : "n"(k), "n"((k) + 3), "n"(q), "n"((q) + 3), YPINS(y) : "memory", OWNED_AGPRS)
 #define MFMA_S_KC(d, k, q, y) asm volatile("v_mfma_f32_32x32x16_bf16 %0, a[%c1:%c2], a[%c3:%c4], %0" : "+v"(d) : "n"(k), "n"((k) + 3), "n"(q), "n"((q) + 3), YPINS(y) : "memory", OWNED_AGPRS)
+// ... carrying one LDS-DMA piece (64 lanes x 16 bytes from sbase + voff[lane] to LDS bytes [lbase + loff, + 1024)): M0 is written in front
+// of the MFMA, which is the wait state the LDS-DMA instruction needs after an M0 write (a stand-alone piece pays an s_nop for it), and as
+// lbase (SGPR: LDS address of this wave's 1 KiB lane of the slots) + a literal, so that the 32 destinations of a four-tile trip do not
+// occupy 32 SGPRs across the loop
+#define MFMA_S0_KC_DMA(d, k, q, y, voff, sbase, lbase, loff) asm volatile("s_add_u32 m0, %7, %8\n\tv_mfma_f32_32x32x16_bf16 %0, a[%c1:%c2], a[%c3:%c4], 0\n\tglobal_load_lds_dwordx4 %5, %6" \
+    : "=&v"(d) : "n"(k), "n"((k) + 3), "n"(q), "n"((q) + 3), "v"(voff), "s"(sbase), "s"(lbase), "n"(loff), YPINS(y) : "memory", "scc", OWNED_AGPRS)
+#define MFMA_S_KC_DMA(d, k, q, y, voff, sbase, lbase, loff) asm volatile("s_add_u32 m0, %7, %8\n\tv_mfma_f32_32x32x16_bf16 %0, a[%c1:%c2], a[%c3:%c4], %0\n\tglobal_load_lds_dwordx4 %5, %6" \
+    : "+v"(d) : "n"(k), "n"((k) + 3), "n"(q), "n"((q) + 3), "v"(voff), "s"(sbase), "s"(lbase), "n"(loff), YPINS(y) : "memory", "scc", OWNED_AGPRS)
+// O += V^T P^T whose statement also names the NEXT gap's V^T fragment: the compiler's wait in front of it then covers both (LDS
+// returns in order) and the next gap needs none
+#define MFMA_O2(o, a, b, a_next, y) asm volatile("v_mfma_f32_32x32x16_bf16 a[%c2:%c3], %0, %1, a[%c2:%c3]" ::"v"(a), "v"(b), "n"(o), "n"((o) + 15), "v"(a_next), YPINS(y) : "memory", OWNED_AGPRS)
 // K fragment F (k-step F>>1, key half F&1) of the K slot at LDS byte offset kb -> a[KC0 + 4F ..]. Untracked by hipcc's s_waitcnt
 // bookkeeping: LDS returns in order, and every such load is followed by V^T fragment reads hipcc does wait for before the
 // phase ends (or by an explicit s_waitcnt lgkmcnt(0) where it is not), so the data is there when the next phase's MFMAs read it.
@@ -150,47 +164,71 @@ struct Blk {             // the compiler-managed part of a block (O^T and Q^T ar
 //   I = 35     : l += sums
 // Pieces 0..31 sit in the 32 MFMA gaps of the phase that computes the OTHER block; 32..35 ("drain") sit in the first four
 // gaps of the next phase. Re-running pieces 0..31 rebuilds exactly the state the drain expects (the redo path).
-template <int I, bool MASK>
+// FAST (the caller's Q carries softmax scale * log2(e); no base at all): the scores are the exponents, p = exp2(s) — the shift piece and
+// the range vote do not exist. Floating point is scale-invariant, so nothing is lost as long as the row sums stay inside the fp32 range;
+// the kernel checks that once per query block at the end and reruns the workgroup on the robust pieces if it does not hold.
+template <int I, bool MASK, bool FAST>
 __device__ __forceinline__ void sm_piece(Soft& z, const f32x16 (&s)[2], u32x4 (&pf)[4], float c, int keyb, int Lk) {
-    if constexpr (I >= 2 && I <= 33) {
-        constexpr int e = I - 2;
-        if constexpr (e == 0) z.sum0 = z.p[0];
-        else if constexpr (e == 1) z.sum1 = z.p[1];
-        else if constexpr ((e & 1) != 0) z.sum1 += z.p[e & 7];
-        else z.sum0 += z.p[e & 7];
-    }
-    if constexpr (I >= 9) {
-        constexpr int g = (I - 9) >> 3, k = (I - 9) & 7;
-        if constexpr (k == 1 || k == 2) {          // swap of pair k - 1
-            const auto r = __builtin_amdgcn_permlane32_swap(z.ev, z.od, false, false);
-            z.w0 = r[0];
-            z.w1 = r[1];
-            pf[g][k - 1] = z.w0;
-            pf[g][2 + k - 1] = z.w1;
-            if constexpr (k == 2) { z.ev = z.w0; z.od = z.w1; }   // nothing stale stays live as a pin (the swap works in place)
+    auto row_sum = [&]() {
+        if constexpr (I >= 2 && I <= 33) {
+            constexpr int e = I - 2;
+            if constexpr (e == 0) z.sum0 = z.p[0];
+            else if constexpr (e == 1) z.sum1 = z.p[1];
+            else if constexpr ((e & 1) != 0) z.sum1 += z.p[e & 7];
+            else z.sum0 += z.p[e & 7];
         }
-        if constexpr (k == 0 || k == 1) {          // cvt_pk of pair k
-            z.ev = pack_bf16x2(z.p[2 * k], z.p[2 * k + 1]);
-            z.od = pack_bf16x2(z.p[4 + 2 * k], z.p[4 + 2 * k + 1]);
+    };
+    auto pack = [&]() {
+        if constexpr (I >= 9) {
+            constexpr int g = (I - 9) >> 3, k = (I - 9) & 7;
+            if constexpr (k == 1 || k == 2) {          // swap of pair k - 1
+                const auto r = __builtin_amdgcn_permlane32_swap(z.ev, z.od, false, false);
+                z.w0 = r[0];
+                z.w1 = r[1];
+                pf[g][k - 1] = z.w0;
+                pf[g][2 + k - 1] = z.w1;
+                if constexpr (k == 2) { z.ev = z.w0; z.od = z.w1; }   // nothing stale stays live as a pin (the swap works in place)
+            }
+            if constexpr (k == 0 || k == 1) {          // cvt_pk of pair k
+                z.ev = pack_bf16x2(z.p[2 * k], z.p[2 * k + 1]);
+                z.od = pack_bf16x2(z.p[4 + 2 * k], z.p[4 + 2 * k + 1]);
+            }
         }
-    }
-    if constexpr (I >= 1 && I <= 32) {
-        constexpr int e = I - 1;
-        float pv = __builtin_amdgcn_exp2f(z.x);
-        if constexpr (MASK) {
-            constexpr int b = e >> 4, r = e & 15;
-            const int key = keyb + 32 * b + (r & 3) + 8 * (r >> 2);
-            pv = key < Lk ? pv : 0.f;
+    };
+    auto expo = [&]() {
+        if constexpr (I >= 1 && I <= 32) {
+            constexpr int e = I - 1;
+            float pv = __builtin_amdgcn_exp2f(FAST ? s[e >> 4][e & 15] : z.x);
+            if constexpr (MASK) {
+                constexpr int b = e >> 4, r = e & 15;
+                const int key = keyb + 32 * b + (r & 3) + 8 * (r >> 2);
+                pv = key < Lk ? pv : 0.f;
+            }
+            z.p[e & 7] = pv;
         }
-        z.p[e & 7] = pv;
-    }
-    if constexpr (I <= 31) z.x = __builtin_fmaf(s[I >> 4][I & 15], c, -z.m_run);
-    if constexpr (I == 31) {
-        // Did the base hold? The exponentials of a tile whose scores exceed the running base by more than 2^13 make the row sum
-        // (or the two values not yet summed) exceed 2^13 — including inf on the first tile, whose base is -1e30. No row maximum
-        // is reduced on this path; the redo path computes it from S, which stays intact until the next phase.
-        const float big = max3f(z.sum0, z.sum1, z.p[30 & 7]);
-        z.need = __any((big > OVERFLOW_SUM) | (z.x > OVERFLOW_LOG2));
+    };
+    if constexpr (FAST) {
+        // without the shift piece the gap's first VALU follows the MFMA statement directly, and hipcc pads whatever it cannot see through
+        // an asm statement: an exponential's result read by the first instruction behind it (trans -> VALU forwarding), a cvt_pk's by a
+        // swap. So: the exponential first whenever the slot it writes is not an input of this piece's cvt_pk (only the k = 0 piece of a
+        // group reads p[0]), the swap never first, and the row sum — whose exponential sat in the middle of the previous gap — last.
+        constexpr bool exp_first = I >= 9 && (((I - 9) & 7) == 1 || ((I - 9) & 7) == 2);
+        if constexpr (exp_first) expo();
+        pack();
+        if constexpr (!exp_first) expo();
+        row_sum();
+    } else {
+        row_sum();
+        pack();
+        expo();
+        if constexpr (I <= 31) z.x = __builtin_fmaf(s[I >> 4][I & 15], c, -z.m_run);
+        if constexpr (I == 31) {
+            // Did the base hold? The exponentials of a tile whose scores exceed the running base by more than 2^13 make the row sum
+            // (or the two values not yet summed) exceed 2^13 — including inf on the first tile, whose base is -1e30. No row maximum
+            // is reduced on this path; the redo path computes it from S, which stays intact until the next phase.
+            const float big = max3f(z.sum0, z.sum1, z.p[30 & 7]);
+            z.need = __any((big > OVERFLOW_SUM) | (z.x > OVERFLOW_LOG2));
+        }
     }
     if constexpr (I == 35) z.l_run += z.sum0 + z.sum1;
 }
@@ -213,7 +251,7 @@ __device__ __forceinline__ void redo_tile(Blk& y, float c, int keyb, int Lk) {
     y.z.m_run = m_new;
     y.z.l_run *= alpha;
     for_regs<YO, 64>([&](auto r) { agpr_scale<decltype(r)::value>(alpha); });
-#define YUME_P(i) sm_piece<i, MASK>(y.z, y.s, y.pf, c, keyb, Lk);
+#define YUME_P(i) sm_piece<i, MASK, false>(y.z, y.s, y.pf, c, keyb, Lk);
     REP32(YUME_P)
 #undef YUME_P
     NOP_PAD();                                          // accvgpr writes -> MFMA C operands
@@ -252,13 +290,6 @@ __device__ __forceinline__ void dma7_init(Dma7& d, const AttnArgs& p, int h, int
 // the explicit s_waitcnt vmcnt(N) + barrier of the tile loop. M0 is written in the statement that uses it.
 __device__ __forceinline__ void glds16(const char* sbase, unsigned voff, unsigned lds_dst) {
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
-}
-
-// one piece of a full tile: j = 0..3 K rows 16j.., j = 4..7 V^T rows 32(j-4)..   (kslot / vslot: LDS byte addresses)
-template <int J>
-__device__ __forceinline__ void dma7_piece(const Dma7& d, const char* kg, const char* vg, unsigned kslot, unsigned vslot, int wave) {
-    if constexpr (J < 4) glds16(kg, d.kof[J], kslot + J * 4096 + wave * 1024);
-    else glds16(vg, d.vof[J - 4], vslot + (J - 4) * 4096 + wave * 1024);
 }
 
 // whole tiles, any tile (the ragged last one clamps its sources; fix7_v zeroes what must be zero afterwards)
@@ -314,6 +345,7 @@ __device__ __forceinline__ void fix7_v(const Dma7& d, const AttnArgs& p, int t, 
 struct Ctx {
     char* smem;
     unsigned lds0;             // LDS byte address of smem
+    unsigned lbase;            // lds0 + wave * 1024: this wave's 1 KiB lane of every 4 KiB quarter slot (LDS-DMA destinations)
     int koff[8], voff[4];      // per-lane fragment offsets inside a K slot / inside V^T slot 0 (VB included)
     float c;                   // softmax scale * log2(e)
     int keyh;                  // 4 * (lane >> 5)
@@ -343,36 +375,51 @@ __device__ __forceinline__ void fill_kcache(const Ctx& cx, int kb) {
 // NKB >= 0: refill the K cache with the K slot at byte offset NKB (compile-time: it folds into the ds_read offsets), fragment f in
 //   gap f + 1, right after its last reader in this phase.
 // DMA: gaps 0..7 issue one LDS-DMA piece each (K tile at kg -> kslot, V^T tile at vg -> vslot).
-template <int XO, int XQ, int YO, bool DO_S, bool DO_PV, bool DRAIN, bool MASKX, bool SM, bool MASKY, bool DMA, int NKB = -1>
+// DK / DV (DMA): byte offsets of the destination K / V^T slots from smem.
+template <bool FAST, int XO, int XQ, int YO, bool DO_S, bool DO_PV, bool DRAIN, bool MASKX, bool SM, bool MASKY, bool DMA, int NKB = -1, int DK = 0, int DV = 0>
 __device__ __forceinline__ void phase(const Ctx& cx, Blk& X, Blk& Y, u32x4 (&ring)[RD], int vb, int jx, int jy,
-                                      const Dma7& dp, const char* kg, const char* vg, unsigned kslot, unsigned vslot) {
+                                      const Dma7& dp, const char* kg, const char* vg) {
+    static_assert(!DMA || DO_S, "the LDS-DMA pieces ride on the score MFMAs of gaps 0..7");
     __builtin_amdgcn_sched_barrier(0);
+#define YUME_DV(i) ((i) < 4 ? dp.kof[(i) & 3] : dp.vof[(i) & 3])
+#define YUME_DS(i) ((i) < 4 ? kg : vg)
+#define YUME_DL(i) (((i) < 4 ? DK : DV) + ((i) & 3) * 4096)
 #define YUME_GAP(i)                                                                                          \
     {                                                                                                        \
         if constexpr (SM && ((i) < 16 ? !DO_S : !DO_PV)) PIN_BLK(Y);                                         \
         if constexpr ((i) < 16) {                                                                            \
-            if constexpr (DO_S) {                                                             \
-                if constexpr (((i) >> 1) == 0) MFMA_S0_KC(X.s[(i) & 1], KC0 + 4 * ((i) & 15), XQ, Y);        \
-                else MFMA_S_KC(X.s[(i) & 1], KC0 + 4 * ((i) & 15), XQ + 4 * ((i) >> 1), Y);                  \
+            if constexpr (DO_S) {                                                                            \
+                if constexpr (((i) >> 1) == 0) {                                                             \
+                    if constexpr (DMA) MFMA_S0_KC_DMA(X.s[(i) & 1], KC0 + 4 * ((i) & 15), XQ, Y, YUME_DV((i) & 7), YUME_DS((i) & 7), cx.lbase, YUME_DL((i) & 7)); \
+                    else MFMA_S0_KC(X.s[(i) & 1], KC0 + 4 * ((i) & 15), XQ, Y);                              \
+                } else if constexpr (DMA && (i) < 8) {                                                       \
+                    MFMA_S_KC_DMA(X.s[(i) & 1], KC0 + 4 * ((i) & 15), XQ + 4 * ((i) >> 1), Y, YUME_DV((i) & 7), YUME_DS((i) & 7), cx.lbase, YUME_DL((i) & 7)); \
+                } else {                                                                                     \
+                    MFMA_S_KC(X.s[(i) & 1], KC0 + 4 * ((i) & 15), XQ + 4 * ((i) >> 1), Y);                   \
+                }                                                                                            \
             }                                                                                                \
-        } else if constexpr (DO_PV) {                                                         \
-            MFMA_O(XO + 16 * (((i) - 16) & 3), ring[(i) & (RD - 1)], X.pf[((i) - 16) >> 2], Y);              \
+        } else if constexpr (DO_PV) {                                                                        \
+            if constexpr (((i) & 1) == 0) MFMA_O2(XO + 16 * (((i) - 16) & 3), ring[(i) & (RD - 1)], X.pf[((i) - 16) >> 2], ring[((i) + 1) & (RD - 1)], Y); \
+            else MFMA_O(XO + 16 * (((i) - 16) & 3), ring[(i) & (RD - 1)], X.pf[((i) - 16) >> 2], Y);          \
         }                                                                                                    \
         if constexpr (DO_PV && (i) + RD >= 16 && (i) + RD < 32) ring[(i) & (RD - 1)] = frag<(((i) + RD) & 15) + 16>(cx, vb); \
         if constexpr (NKB >= 0 && (i) >= 1 && (i) <= 16)                                       \
             LOAD_KC(((i) - 1) & 15, cx.koff[(((i) - 1) & 15) >> 1], (NKB < 0 ? 0 : NKB) + ((((i) - 1) & 1) ? 32 * 256 : 0)); \
-        if constexpr (DMA && (i) < 8) dma7_piece<(i) & 7>(dp, kg, vg, kslot, vslot, cx.wave);  \
         if constexpr (DRAIN && (i) >= 1 && (i) < 5) PIN_BLK(X);     /* drain piece of the previous gap stays there */ \
-        if constexpr (DRAIN && (i) < 4) sm_piece<32 + ((i) & 3), MASKX>(X.z, X.s, X.pf, cx.c, jx + cx.keyh, cx.Lk); \
-        if constexpr (SM) sm_piece<(i), MASKY>(Y.z, Y.s, Y.pf, cx.c, jy + cx.keyh, cx.Lk);     \
+        if constexpr (DRAIN && (i) < 4) sm_piece<32 + ((i) & 3), MASKX, FAST>(X.z, X.s, X.pf, cx.c, jx + cx.keyh, cx.Lk); \
+        if constexpr (SM) sm_piece<(i), MASKY, FAST>(Y.z, Y.s, Y.pf, cx.c, jy + cx.keyh, cx.Lk);     \
         __builtin_amdgcn_sched_barrier(0);                                                                   \
     }
     REP32(YUME_GAP)
 #undef YUME_GAP
+#undef YUME_DV
+#undef YUME_DS
+#undef YUME_DL
     if constexpr (NKB >= 0 && !DO_PV) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // no V^T reads behind the K loads to order them
     if constexpr (SM) {
         PIN_BLK(Y);
-        if (__builtin_expect(Y.z.need, 0)) redo_tile<YO, MASKY>(Y, cx.c, jy + cx.keyh, cx.Lk);
+        if constexpr (!FAST)
+            if (__builtin_expect(Y.z.need, 0)) redo_tile<YO, MASKY>(Y, cx.c, jy + cx.keyh, cx.Lk);
     }
 }
 
@@ -407,16 +454,18 @@ __device__ __forceinline__ void store_block(const AttnArgs& p, const Blk& x, int
 }
 
 // Q^T fragments of the block's query (lane (q, hi) holds Q[q][16*ks + 8*hi .. +7]) -> a[XQ + 4*ks ..]; O^T = 0; softmax state
-template <int XO, int XQ>
+template <int XO, int XQ, bool FAST, bool RELOAD = true>
 __device__ __forceinline__ void load_q(const AttnArgs& p, Blk& x, int q, int h, int hi) {
-    q = q < p.Lq ? q : p.Lq - 1;
-    const unsigned short* qp = p.Q + (int64_t)q * p.ldq + h * D + 8 * hi;
-    u32x4 qf[8];
+    if constexpr (RELOAD) {               // (the rerun on the robust pieces finds Q^T where the first pass left it)
+        q = q < p.Lq ? q : p.Lq - 1;
+        const unsigned short* qp = p.Q + (int64_t)q * p.ldq + h * D + 8 * hi;
+        u32x4 qf[8];
 #pragma unroll
-    for (int ks = 0; ks < 8; ++ks) qf[ks] = *reinterpret_cast<const u32x4*>(qp + 16 * ks);
-    for_regs<0, 32>([&](auto r) { agpr_set<XQ + decltype(r)::value>(qf[decltype(r)::value >> 2][decltype(r)::value & 3]); });
+        for (int ks = 0; ks < 8; ++ks) qf[ks] = *reinterpret_cast<const u32x4*>(qp + 16 * ks);
+        for_regs<0, 32>([&](auto r) { agpr_set<XQ + decltype(r)::value>(qf[decltype(r)::value >> 2][decltype(r)::value & 3]); });
+    }
     for_regs<XO, 64>([&](auto r) { agpr_set<decltype(r)::value>(0u); });
-    x.z.m_run = NEG_BIG;
+    x.z.m_run = FAST ? 0.f : NEG_BIG;
     x.z.l_run = 0.f;
     x.z.need = 0;
     x.z.sum0 = x.z.sum1 = 0.f;
@@ -427,21 +476,22 @@ __device__ __forceinline__ void load_q(const AttnArgs& p, Blk& x, int q, int h, 
 }
 
 // steady-state tile t (TS = t % 4): 1 <= t, t + 4 < number of FULL tiles; every LDS address is a compile-time constant
-template <int TS>
-__device__ __forceinline__ void steady7(const Ctx& cx, const Dma7& dp, int t, Blk& A, Blk& B, u32x4 (&ring)[RD]) {
+// kg / vg: DMA sources of K(t+4) / V^T(t+3), advanced by one tile here (two SALU adds each instead of a 64-bit product per tile)
+template <int TS, bool FAST>
+__device__ __forceinline__ void steady7(const Ctx& cx, const Dma7& dp, const char*& kg, const char*& vg, int64_t kstep, Blk& A, Blk& B, u32x4 (&ring)[RD]) {
     constexpr int vb = TS * SLOT, nkb = ((TS + 2) & 3) * SLOT;      // V^T(t); K(t+2) for the cache refill (K(t+1) is in the cache)
-    const char* kg = dp.kbase + (int64_t)(t + 4) * KT * dp.krow;
-    const char* vg = dp.vbase + (int64_t)(t + 3) * KT * 2;
-    const unsigned kslot = cx.lds0 + TS * SLOT;
-    const unsigned vslot = cx.lds0 + VB + ((TS + 3) & 3) * SLOT;
+    constexpr int dk = TS * SLOT, dv = VB + ((TS + 3) & 3) * SLOT;      // K(t+4) takes K(t)'s slot, V^T(t+3) the slot V^T(t-1) left
     asm volatile("s_waitcnt vmcnt(8)" ::: "memory");      // everything older than the previous tile's 8 pieces has landed
     __builtin_amdgcn_s_barrier();
-    phase<OA, QA, OB, true, true, true, false, true, false, true>(cx, A, B, ring, vb, 0, 0, dp, kg, vg, kslot, vslot);
-    phase<OB, QB, OA, true, true, true, false, true, false, false, nkb>(cx, B, A, ring, vb, 0, 0, dp, kg, vg, kslot, vslot);
+    phase<FAST, OA, QA, OB, true, true, true, false, true, false, true, -1, dk, dv>(cx, A, B, ring, vb, 0, 0, dp, kg, vg);
+    phase<FAST, OB, QB, OA, true, true, true, false, true, false, false, nkb>(cx, B, A, ring, vb, 0, 0, dp, kg, vg);
+    kg += kstep;
+    vg += KT * 2;
 }
 
 // any tile t of the range [.., t1) (runtime slots; the softmax pieces always carry the key mask). nt / ragged describe the whole key
 // sequence: only its last tile can be ragged.
+template <bool FAST>
 __device__ __forceinline__ void general7(const Ctx& cx, const Dma7& dp, const AttnArgs& p, int t, int t0, int t1, int nt, bool ragged, int tid,
                                          Blk& A, Blk& B, u32x4 (&ring)[RD]) {
     const int last = nt - 1;
@@ -455,11 +505,11 @@ __device__ __forceinline__ void general7(const Ctx& cx, const Dma7& dp, const At
     const int j = t * KT;
     if (t + 1 < t1) {
         fill_kcache(cx, ((t + 1) & 3) * SLOT);            // K(t+1), published by the barrier above
-        phase<OA, QA, OB, true, true, true, true, true, true, false>(cx, A, B, ring, vb, j, j, dp, nullptr, nullptr, 0u, 0u);
-        phase<OB, QB, OA, true, true, true, true, true, true, false>(cx, B, A, ring, vb, j, j + KT, dp, nullptr, nullptr, 0u, 0u);
+        phase<FAST, OA, QA, OB, true, true, true, true, true, true, false>(cx, A, B, ring, vb, j, j, dp, nullptr, nullptr);
+        phase<FAST, OB, QB, OA, true, true, true, true, true, true, false>(cx, B, A, ring, vb, j, j + KT, dp, nullptr, nullptr);
     } else {
-        phase<OA, QA, OB, false, true, true, true, true, true, false>(cx, A, B, ring, vb, j, j, dp, nullptr, nullptr, 0u, 0u);
-        phase<OB, QB, OA, false, true, true, true, false, true, false>(cx, B, A, ring, vb, j, j, dp, nullptr, nullptr, 0u, 0u);
+        phase<FAST, OA, QA, OB, false, true, true, true, true, true, false>(cx, A, B, ring, vb, j, j, dp, nullptr, nullptr);
+        phase<FAST, OB, QB, OA, false, true, true, true, false, true, false>(cx, B, A, ring, vb, j, j, dp, nullptr, nullptr);
     }
 }
 
@@ -485,8 +535,84 @@ __device__ __forceinline__ void store_partial(const AttnArgs& p, const Blk& x, i
     }
 }
 
+// One pass over the key range [t0, t1) for the workgroup's 256 queries: Q^T / O^T / softmax state set up, prologue DMA, the tile loop.
+// FAST: see sm_piece. RELOAD = false: Q^T is still in its AGPRs (the robust rerun of a FAST pass).
+template <bool FAST, bool RELOAD>
+__device__ __forceinline__ void run_keys(const AttnArgs& p, const Ctx& cx, const Dma7& dp, Blk& A, Blk& B, int q0, int ql, int h, int hi,
+                                         int t0, int t1, int nt, int tid) {
+    const int wave = cx.wave;
+    const bool ragged = (p.Lk % KT) != 0;
+    const int last = nt - 1;
+    const int tsteady = (ragged && t1 == nt) ? t1 - 1 : t1;      // tiles below this index are full AND inside the range
+    load_q<OA, QA, FAST, RELOAD>(p, A, q0 + ql, h, hi);
+    load_q<OB, QB, FAST, RELOAD>(p, B, q0 + 32 + ql, h, hi);
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- prologue DMA: K(t0) | K(t0+1) V(t0) | K(t0+2) V(t0+1) | K(t0+3) V(t0+2) ----
+    dma7_k(dp, p, t0, ragged && last == t0, cx.lds0 + (t0 & 3) * SLOT, wave);
+    if (t0 + 1 < t1) dma7_k(dp, p, t0 + 1, ragged && last == t0 + 1, cx.lds0 + ((t0 + 1) & 3) * SLOT, wave);
+    dma7_v(dp, p, t0, ragged && last == t0, cx.lds0 + VB + (t0 & 3) * SLOT, wave);
+    if (t0 + 2 < t1) dma7_k(dp, p, t0 + 2, ragged && last == t0 + 2, cx.lds0 + ((t0 + 2) & 3) * SLOT, wave);
+    if (t0 + 1 < t1) dma7_v(dp, p, t0 + 1, ragged && last == t0 + 1, cx.lds0 + VB + ((t0 + 1) & 3) * SLOT, wave);
+    if (t0 + 3 < t1) dma7_k(dp, p, t0 + 3, ragged && last == t0 + 3, cx.lds0 + ((t0 + 3) & 3) * SLOT, wave);
+    if (t0 + 2 < t1) dma7_v(dp, p, t0 + 2, ragged && last == t0 + 2, cx.lds0 + VB + ((t0 + 2) & 3) * SLOT, wave);
+
+    __builtin_amdgcn_sched_barrier(0);
+    if (t0 + 3 < t1) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");      // K(t0) has landed (the Q loads are older still)
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    NOP_PAD();
+
+    u32x4 ring[RD];
+    // S_A(t0), then S_B(t0) beside softmax_A(t0)
+    {
+        const int j0 = t0 * KT;
+        fill_kcache(cx, (t0 & 3) * SLOT);
+        phase<FAST, OA, QA, OB, true, false, false, true, false, true, false>(cx, A, B, ring, 0, j0, j0, dp, nullptr, nullptr);
+        phase<FAST, OB, QB, OA, true, false, false, true, true, true, false>(cx, B, A, ring, 0, j0, j0, dp, nullptr, nullptr);
+    }
+
+    int t = t0;
+#pragma unroll 1
+    while (t < t1) {
+        if (t > t0 && (t & 3) == 1 && t + 7 < tsteady) {
+            fill_kcache(cx, 2 * SLOT);          // K(t+1) (slot 2 here), published by the barrier of the previous tile
+            // A's score registers are dead here and the loop's first MFMAs overwrite them. Claim them NOW: if hipcc parked a spill
+            // reload in them on the way here, its wait for that load lands in front of the loop instead of inside it, where an
+            // s_waitcnt vmcnt(0) would also wait for every LDS-DMA piece in flight (tests/test_attn7_isa.py checks the loop).
+            asm volatile("" : "=v"(A.s[0]), "=v"(A.s[1]));
+            const int64_t kstep = (int64_t)KT * dp.krow;
+            const char* kg = dp.kbase + (int64_t)(t + 4) * kstep;
+            const char* vg = dp.vbase + (int64_t)(t + 3) * KT * 2;
+#pragma unroll 1
+            for (; t + 7 < tsteady; t += 4) {        // t % 4 == 1; the four calls issue tiles up to t + 7 (all full, all in range)
+                steady7<1, FAST>(cx, dp, kg, vg, kstep, A, B, ring);
+                steady7<2, FAST>(cx, dp, kg, vg, kstep, A, B, ring);
+                steady7<3, FAST>(cx, dp, kg, vg, kstep, A, B, ring);
+                steady7<0, FAST>(cx, dp, kg, vg, kstep, A, B, ring);
+            }
+        } else {
+            general7<FAST>(cx, dp, p, t, t0, t1, nt, ragged, tid, A, B, ring);
+            ++t;
+        }
+    }
+    NOP_PAD();
+}
+
+// FAST pass only: did every row of this wave's block stay inside the range? The row sum has to be finite (an overflowing exponential —
+// a score above 127 — makes it inf) and not tiny (a row whose scores all sit below about -100 loses its small terms to the flush-to-zero
+// of exp2, or sums to 0), and no O^T element may be inf / NaN (0 * x summed over the block is 0 exactly when every x is finite).
+template <int XO>
+__device__ __forceinline__ bool block_in_range(const Blk& x) {
+    const float l_tot = xhalf_sum(x.z.l_run);
+    float z = 0.f;
+    for_regs<0, 64>([&](auto r) { z = __builtin_fmaf(agpr_get<XO + decltype(r)::value>(), 0.f, z); });
+    return (l_tot > 0x1p-100f) & (l_tot < 0x1p126f) & (z == 0.f);
+}
+
+// PRE: Q already carries softmax scale * log2(e) (AttnArgs::q_prescaled; scale_log2 is 1): the FAST pieces run first.
+template <bool PRE>
 __global__ __launch_bounds__(256, 1) void attn_fwd_kernel_v7(AttnArgs p) {
-    __shared__ __attribute__((aligned(16))) char smem[LDS7];
+    __shared__ __attribute__((aligned(16))) char smem[LDS7 + 16];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -520,6 +646,7 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_kernel_v7(AttnArgs p) {
     Ctx cx;
     cx.smem = smem;
     cx.lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    cx.lbase = cx.lds0 + wave * 1024;
     cx.c = p.scale_log2;
     cx.keyh = 4 * hi;
     cx.Lk = p.Lk;
@@ -531,61 +658,26 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_kernel_v7(AttnArgs p) {
 
     Dma7 dp;
     dma7_init(dp, p, h, tid);
-    const bool ragged = (p.Lk % KT) != 0;
-    const int last = nt - 1;
-    const int tsteady = (ragged && t1 == nt) ? t1 - 1 : t1;      // tiles below this index are full AND inside the range
 
     Blk A, B;
-    load_q<OA, QA>(p, A, q0 + ql, h, hi);
-    load_q<OB, QB>(p, B, q0 + 32 + ql, h, hi);
-    __builtin_amdgcn_sched_barrier(0);
-    // ---- prologue DMA: K(t0) | K(t0+1) V(t0) | K(t0+2) V(t0+1) | K(t0+3) V(t0+2) ----
-    dma7_k(dp, p, t0, ragged && last == t0, cx.lds0 + (t0 & 3) * SLOT, wave);
-    if (t0 + 1 < t1) dma7_k(dp, p, t0 + 1, ragged && last == t0 + 1, cx.lds0 + ((t0 + 1) & 3) * SLOT, wave);
-    dma7_v(dp, p, t0, ragged && last == t0, cx.lds0 + VB + (t0 & 3) * SLOT, wave);
-    if (t0 + 2 < t1) dma7_k(dp, p, t0 + 2, ragged && last == t0 + 2, cx.lds0 + ((t0 + 2) & 3) * SLOT, wave);
-    if (t0 + 1 < t1) dma7_v(dp, p, t0 + 1, ragged && last == t0 + 1, cx.lds0 + VB + ((t0 + 1) & 3) * SLOT, wave);
-    if (t0 + 3 < t1) dma7_k(dp, p, t0 + 3, ragged && last == t0 + 3, cx.lds0 + ((t0 + 3) & 3) * SLOT, wave);
-    if (t0 + 2 < t1) dma7_v(dp, p, t0 + 2, ragged && last == t0 + 2, cx.lds0 + VB + ((t0 + 2) & 3) * SLOT, wave);
-
-    __builtin_amdgcn_sched_barrier(0);
-    if (t0 + 3 < t1) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");      // K(t0) has landed (the Q loads are older still)
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    NOP_PAD();
-
-    u32x4 ring[RD];
-    // S_A(t0), then S_B(t0) beside softmax_A(t0)
-    {
-        const int j0 = t0 * KT;
-        fill_kcache(cx, (t0 & 3) * SLOT);
-        phase<OA, QA, OB, true, false, false, true, false, true, false>(cx, A, B, ring, 0, j0, j0, dp, nullptr, nullptr, 0u, 0u);
-        phase<OB, QB, OA, true, false, false, true, true, true, false>(cx, B, A, ring, 0, j0, j0, dp, nullptr, nullptr, 0u, 0u);
-    }
-
-    int t = t0;
-#pragma unroll 1
-    while (t < t1) {
-        if (t > t0 && (t & 3) == 1 && t + 7 < tsteady) {
-            fill_kcache(cx, 2 * SLOT);          // K(t+1) (slot 2 here), published by the barrier of the previous tile
-            // A's score registers are dead here and the loop's first MFMAs overwrite them. Claim them NOW: if hipcc parked a spill
-            // reload in them on the way here, its wait for that load lands in front of the loop instead of inside it, where an
-            // s_waitcnt vmcnt(0) would also wait for every LDS-DMA piece in flight (tests/test_attn7_isa.py checks the loop).
-            asm volatile("" : "=v"(A.s[0]), "=v"(A.s[1]));
-#pragma unroll 1
-            for (; t + 7 < tsteady; t += 4) {        // t % 4 == 1; the four calls issue tiles up to t + 7 (all full, all in range)
-                steady7<1>(cx, dp, t, A, B, ring);
-                steady7<2>(cx, dp, t + 1, A, B, ring);
-                steady7<3>(cx, dp, t + 2, A, B, ring);
-                steady7<0>(cx, dp, t + 3, A, B, ring);
-            }
-        } else {
-            general7(cx, dp, p, t, t0, t1, nt, ragged, tid, A, B, ring);
-            ++t;
+    if constexpr (PRE) {
+        run_keys<true, true>(p, cx, dp, A, B, q0, ql, h, hi, t0, t1, nt, tid);
+        // one vote per workgroup (the tile loop is a workgroup affair: shared K / V^T slots, barriers): rerun on the robust pieces?
+        const bool ok = block_in_range<OA>(A) & block_in_range<OB>(B);
+        int* votes = reinterpret_cast<int*>(smem + LDS7);
+        const int wave_ok = __all(ok) ? 1 : 0;        // (outside the lane-0 branch: the vote is over the whole wave)
+        if (lane == 0) votes[wave] = wave_ok;
+        __syncthreads();
+        const int all_ok = votes[0] & votes[1] & votes[2] & votes[3];
+        __syncthreads();
+        if (__builtin_expect(!__builtin_amdgcn_readfirstlane(all_ok), 0)) {
+            cx.c = 1.0f;
+            run_keys<false, false>(p, cx, dp, A, B, q0, ql, h, hi, t0, t1, nt, tid);
         }
+    } else {
+        run_keys<false, true>(p, cx, dp, A, B, q0, ql, h, hi, t0, t1, nt, tid);
     }
 
-    NOP_PAD();
     if (nsp > 1) {
         const int row0 = p.q_lo + p.tail_qb * QB7;
         const int64_t rows = p.Lq - row0;
@@ -603,5 +695,6 @@ void yume_attn7_launch(const AttnArgs& a, hipStream_t st) {
     // every XCD slot gets ceil(H/8) * (whole blocks + pieces) block ids; surplus ids exit immediately
     const int64_t per = (int64_t)a.tail_qb + (int64_t)(a.nqb - a.tail_qb) * a.splits;
     const dim3 grid((unsigned)(((a.H + 7) / 8) * per * 8));
-    hipLaunchKernelGGL(attn_fwd_kernel_v7, grid, dim3(256), 0, st, a);
+    if (a.q_prescaled) hipLaunchKernelGGL(attn_fwd_kernel_v7<true>, grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(attn_fwd_kernel_v7<false>, grid, dim3(256), 0, st, a);
 }

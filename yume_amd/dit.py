@@ -18,6 +18,9 @@ HBM layout (L tokens, C hidden): residual stream x fp32 [L, C]; GEMM operands bf
 q|k bf16 [L, 2C]; V^T bf16 [C, Lpad] (K-major, per head 128 rows); modulation tables fp32 [blocks, R, 6, C].
 """
 
+import math
+import os
+
 import torch
 
 from . import framepack, ops
@@ -45,6 +48,10 @@ class DiTEngine:
         # whole model on the independent 128x128-tile GEMM and register-staged attention kernels as a cross-check
         self.gemm_variant = 0
         self.attn_variant = 0
+        # self-attention q leaves yume_rmsnorm_rope already multiplied by softmax scale * log2(e) (folded into the fp32 RMSNorm weight of q,
+        # i.e. before q's one bf16 rounding) and yume_attn_fwd is told so (YUME_ATTN_Q_PRESCALED): the scores are the exponents.
+        # YUME_ATTN_PRESCALE=0 keeps the scale inside the attention kernel (A/B and cross-checks).
+        self.q_prescale = os.environ.get("YUME_ATTN_PRESCALE", "1") != "0"
         # a yume_amd.ulysses.SequenceParallel splits ONE chain's tokens over the ranks of its group
         self.sp = None
         self._ctx_key = None
@@ -67,7 +74,7 @@ class DiTEngine:
     def _param_key(self):
         # walked once per forward: (storage address, in-place version, dtype) of every parameter — a load_state_dict, an
         # optimizer step or a .to(dtype) re-packs; cheap next to one forward (≈1 k tensors), and cached per forward call
-        return tuple((p.data_ptr(), p._version, p.dtype) for p in self.model.parameters())
+        return (self.q_prescale,) + tuple((p.data_ptr(), p._version, p.dtype) for p in self.model.parameters())
 
     def _pack(self):
         m = self.model
@@ -110,12 +117,13 @@ class DiTEngine:
             P["img"] = (f32(pr[0].weight), f32(pr[0].bias), bf(pr[1].weight), f32(pr[1].bias), bf(pr[3].weight),
                         f32(pr[3].bias), f32(pr[4].weight), f32(pr[4].bias))
         blocks = []
+        qs = math.log2(math.e) / math.sqrt(C // m.num_heads) if self.q_prescale else 1.0
         for b in m.blocks:
             sa, ca = b.self_attn, b.cross_attn
             d = {
                 "wqkv": bf(torch.cat([sa.q.weight, sa.k.weight, sa.v.weight], dim=0)),
                 "bqkv": f32(torch.cat([sa.q.bias, sa.k.bias, sa.v.bias])),
-                "nqk": f32(torch.cat([sa.norm_q.weight, sa.norm_k.weight])),
+                "nqk": f32(torch.cat([sa.norm_q.weight.double() * qs, sa.norm_k.weight.double()])),
                 "wo": bf(sa.o.weight), "bo": f32(sa.o.bias),
                 "wq_c": bf(ca.q.weight), "bq_c": f32(ca.q.bias), "nq_c": f32(ca.norm_q.weight),
                 "wo_c": bf(ca.o.weight), "bo_c": f32(ca.o.bias),
@@ -297,12 +305,13 @@ class DiTEngine:
                 ops.rmsnorm_rope(qk[:n_rope], C, 2, d["nqk"], eps, rope)
                 ops.rmsnorm_rope(qk[n_rope:], C, 2, d["nqk"], eps, None)
             if self.sp is None:
-                T("attn_self", ops.attn_fwd, qk[:, :C], qk[:, C:], vt, att, L, n_keys if n_keys is not None else L, H, variant=self.attn_variant)
+                T("attn_self", ops.attn_fwd, qk[:, :C], qk[:, C:], vt, att, L, n_keys if n_keys is not None else L, H, variant=self.attn_variant,
+                  q_prescaled=self.q_prescale)
                 sa = att
             else:      # Ulysses: all tokens x this rank's heads, then back (2 collectives, yume_amd/ulysses.py)
                 qf, kf, vtf = self.sp.exchange_qkv(qk, vt, C)
                 of = self._buf("att_sp", (qf.shape[0], qf.shape[1]), torch.bfloat16)
-                ops.attn_fwd(qf, kf, vtf, of, qf.shape[0], n_keys, H // self.sp.world, variant=self.attn_variant)
+                ops.attn_fwd(qf, kf, vtf, of, qf.shape[0], n_keys, H // self.sp.world, variant=self.attn_variant, q_prescaled=self.q_prescale)
                 sa = self.sp.exchange_out(of)
             T("gemm_o", ops.gemm_bf16, sa, d["wo"], d["bo"], xs, EPI_RESID, gate=gate_sa, gate_stride=ts, row_idx=row_idx, variant=self.gemm_variant)
             # --- cross attention

@@ -131,8 +131,12 @@ def rmsnorm_rows_periodic(buf, C, w, eps=1e-6):
 _attn_ws, _attn_ws_bytes = {}, {}
 
 
-def attn_fwd(q, k, vt, out, Lq, Lk, H, scale=None, accumulate=False, variant=0, use_workspace=True):
-    """out[Lq, H*128] = softmax(q k^T * scale) v ; q,k token-major bf16 2-D views, vt K-major [H*128, >=Lk]."""
+ATTN_Q_PRESCALED = 0x100     # YUME_ATTN_Q_PRESCALED
+
+
+def attn_fwd(q, k, vt, out, Lq, Lk, H, scale=None, accumulate=False, variant=0, use_workspace=True, q_prescaled=False):
+    """out[Lq, H*128] = softmax(q k^T * scale) v ; q,k token-major bf16 2-D views, vt K-major [H*128, >=Lk].
+    q_prescaled: q already carries scale * log2(e) (`scale` is ignored): out = sum_j 2^(q.k_j) v_j / sum_j 2^(q.k_j)."""
     lib = _lib.load()
     _dev(q, "q", torch.bfloat16)
     _dev(k, "k", torch.bfloat16)
@@ -155,8 +159,8 @@ def attn_fwd(q, k, vt, out, Lq, Lk, H, scale=None, accumulate=False, variant=0, 
             ws = _attn_ws.get(wkey)
             if ws is None or ws.numel() < nbytes:
                 ws = _attn_ws[wkey] = torch.empty(nbytes, dtype=torch.uint8, device=q.device)
-    rc = lib.yume_attn_fwd_ws(qp, ldq, kp, ldk, vp, ldv, op, ldo, Lq, Lk, H, scale, 1 if accumulate else 0, variant,
-                              _ptr(ws), nbytes if ws is not None else 0, _stream())
+    rc = lib.yume_attn_fwd_ws(qp, ldq, kp, ldk, vp, ldv, op, ldo, Lq, Lk, H, scale, 1 if accumulate else 0,
+                              variant | (ATTN_Q_PRESCALED if q_prescaled else 0), _ptr(ws), nbytes if ws is not None else 0, _stream())
     _lib.check(rc, "yume_attn_fwd")
     return out
 
