@@ -26,20 +26,39 @@ def main():
     res = {}
     nlat = int(os.environ.get("YUME_VAE_LATENTS", "8"))
     z = torch.randn(48, nlat, 44, 80, device=dev, generator=g)
+    # the reference's walk (one latent frame per decoder pass) next to the grouped passes: same outputs?
+    eng = m.engine
+    group = eng.group
+    eng.group = 1
+    for it in range(2):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        ref = vae.decode([z])[0]
+        torch.cuda.synchronize(); dt = time.perf_counter() - t0
+        print(f"decode {nlat} latents, one per pass -> {tuple(ref.shape)}: {dt*1e3:.1f} ms  ({nlat/dt:.2f} latents/s)", flush=True)
+    res["decode_ms_group1"] = dt * 1e3
+    eng.group = group
     for it in range(2):
         torch.cuda.synchronize(); t0 = time.perf_counter()
         out = vae.decode([z])[0]
         torch.cuda.synchronize(); dt = time.perf_counter() - t0
-        print(f"decode {nlat} latents -> {tuple(out.shape)}: {dt*1e3:.1f} ms  ({nlat/dt:.2f} latents/s)  finite={bool(torch.isfinite(out).all())}", flush=True)
+        print(f"decode {nlat} latents, group {group} -> {tuple(out.shape)}: {dt*1e3:.1f} ms  ({nlat/dt:.2f} latents/s)  finite={bool(torch.isfinite(out).all())}", flush=True)
+    d = (out - ref).abs().max().item()
+    print(f"grouped vs one-per-pass: max abs diff {d:.3e} (output rms {ref.pow(2).mean().sqrt().item():.3f}), equal bits: {bool(torch.equal(out, ref))}", flush=True)
+    res["group_vs_walk_maxabs"] = d
+    del ref
     res["decode_ms"] = dt * 1e3; res["decode_latents_per_s"] = nlat / dt
     res["decode_tflops"] = (485.04 if nlat == 8 else None) and 485.04 / dt / 1e0 / 1e0 if nlat == 8 else None
     video = torch.rand(3, 17, 704, 1280, device=dev, generator=g) * 2 - 1
+    eng.group = 1
+    lat1 = vae.encode([video])[0]
+    eng.group = group
     for it in range(2):
         torch.cuda.synchronize(); t0 = time.perf_counter()
         lat = vae.encode([video])[0]
         torch.cuda.synchronize(); dt = time.perf_counter() - t0
         print(f"encode 17 frames -> {tuple(lat.shape)}: {dt*1e3:.1f} ms", flush=True)
     res["encode17_ms"] = dt * 1e3
+    print(f"encode grouped vs chunk walk: max abs diff {(lat - lat1).abs().max().item():.3e}, equal bits: {bool(torch.equal(lat, lat1))}", flush=True)
     print("peak mem GB", torch.cuda.max_memory_allocated() / 1e9)
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     json.dump(res, open(os.path.join(ROOT, "gpurun_out", "vae_probe.json"), "w"))

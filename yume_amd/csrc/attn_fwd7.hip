@@ -491,13 +491,30 @@ __device__ __forceinline__ void steady7(const Ctx& cx, const Dma7& dp, const cha
 
 // any tile t of the range [.., t1) (runtime slots; the softmax pieces always carry the key mask). nt / ragged describe the whole key
 // sequence: only its last tile can be ragged.
-template <bool FAST>
+// s_waitcnt vmcnt(n), n a multiple of 4 up to 16 (wave-uniform)
+__device__ __forceinline__ void wait_vm(int n) {
+    if (n >= 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else if (n >= 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else if (n >= 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (n >= 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// any tile t of the range [.., t1) (runtime slots). nt / ragged describe the whole key sequence: only its last tile can be ragged, and
+// only the pieces of tiles t and t + 1 are touched here — MASK = false when neither is that tile.
+template <bool FAST, bool MASK>
 __device__ __forceinline__ void general7(const Ctx& cx, const Dma7& dp, const AttnArgs& p, int t, int t0, int t1, int nt, bool ragged, int tid,
                                          Blk& A, Blk& B, u32x4 (&ring)[RD]) {
     const int last = nt - 1;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // This tile reads V^T(t) and K(t+1). LDS-DMA pieces land in issue order, so whatever was issued behind those two may stay in flight:
+    // after the prologue (K0 | K1 V0 | K2 V1 | K3 V2) that is K(t0+2), V^T(t0+1), K(t0+3), V^T(t0+2); otherwise what tile t-1 issued,
+    // K(t+3) and V^T(t+2) — as far as those tiles exist.
+    int keep = t == t0 ? 4 * ((t0 + 2 < t1) + (t0 + 1 < t1) + (t0 + 3 < t1) + (t0 + 2 < t1)) : 4 * ((t + 3 < t1) + (t + 2 < t1));
     // V^T(last) was issued three tiles ago (or in the prologue): zero its keys >= Lk before the barrier that precedes its first read
-    if (ragged && t1 == nt && t == (last - 2 > t0 ? last - 2 : t0)) fix7_v(dp, p, last, cx.smem + VB + (last & 3) * SLOT, tid);
+    const bool fix = ragged && t1 == nt && t == (last - 2 > t0 ? last - 2 : t0);
+    if (fix) keep = 0;
+    wait_vm(keep);
+    if (fix) fix7_v(dp, p, last, cx.smem + VB + (last & 3) * SLOT, tid);
     __builtin_amdgcn_s_barrier();
     if (t + 4 < t1) dma7_k(dp, p, t + 4, ragged && t + 4 == last, cx.lds0 + ((t + 4) & 3) * SLOT, cx.wave);
     if (t + 3 < t1) dma7_v(dp, p, t + 3, ragged && t + 3 == last, cx.lds0 + VB + ((t + 3) & 3) * SLOT, cx.wave);
@@ -505,11 +522,11 @@ __device__ __forceinline__ void general7(const Ctx& cx, const Dma7& dp, const At
     const int j = t * KT;
     if (t + 1 < t1) {
         fill_kcache(cx, ((t + 1) & 3) * SLOT);            // K(t+1), published by the barrier above
-        phase<FAST, OA, QA, OB, true, true, true, true, true, true, false>(cx, A, B, ring, vb, j, j, dp, nullptr, nullptr);
-        phase<FAST, OB, QB, OA, true, true, true, true, true, true, false>(cx, B, A, ring, vb, j, j + KT, dp, nullptr, nullptr);
+        phase<FAST, OA, QA, OB, true, true, true, MASK, true, MASK, false>(cx, A, B, ring, vb, j, j, dp, nullptr, nullptr);
+        phase<FAST, OB, QB, OA, true, true, true, MASK, true, MASK, false>(cx, B, A, ring, vb, j, j + KT, dp, nullptr, nullptr);
     } else {
-        phase<FAST, OA, QA, OB, false, true, true, true, true, true, false>(cx, A, B, ring, vb, j, j, dp, nullptr, nullptr);
-        phase<FAST, OB, QB, OA, false, true, true, true, false, true, false>(cx, B, A, ring, vb, j, j, dp, nullptr, nullptr);
+        phase<FAST, OA, QA, OB, false, true, true, MASK, true, MASK, false>(cx, A, B, ring, vb, j, j, dp, nullptr, nullptr);
+        phase<FAST, OB, QB, OA, false, true, true, MASK, false, MASK, false>(cx, B, A, ring, vb, j, j, dp, nullptr, nullptr);
     }
 }
 
@@ -591,7 +608,8 @@ __device__ __forceinline__ void run_keys(const AttnArgs& p, const Ctx& cx, const
                 steady7<0, FAST>(cx, dp, kg, vg, kstep, A, B, ring);
             }
         } else {
-            general7<FAST>(cx, dp, p, t, t0, t1, nt, ragged, tid, A, B, ring);
+            if (ragged && t + 1 >= last) general7<FAST, true>(cx, dp, p, t, t0, t1, nt, ragged, tid, A, B, ring);
+            else general7<FAST, false>(cx, dp, p, t, t0, t1, nt, ragged, tid, A, B, ring);
             ++t;
         }
     }
