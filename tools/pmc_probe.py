@@ -16,7 +16,7 @@ wo = bf(C, C) * 0.05
 wqkv, bqkv = bf(3 * C, C) * 0.05, torch.randn(3 * C, device=DEV)
 qk = torch.empty(L, 2 * C, dtype=torch.bfloat16, device=DEV)
 vt = torch.empty(C, (L + 7) // 8 * 8, dtype=torch.bfloat16, device=DEV)
-q, k = bf(L, C), bf(L, C)
+q, k = (bf(L, C).float() * (2.0 * 0.12753)).to(torch.bfloat16), bf(L, C) * 2.0     # q as the engine hands it over: times scale * log2(e)
 oa = torch.empty(L, C, dtype=torch.bfloat16, device=DEV)
 xs = torch.randn(L, C, device=DEV)
 tab = torch.randn(2, 6, C, device=DEV)
@@ -29,7 +29,7 @@ cb = torch.zeros(256, device=DEV); co = torch.empty(4, 352, 640, 256, dtype=torc
 zero = torch.zeros(64, dtype=torch.bfloat16, device=DEV)
 for it in range(3):
     ops.gemm_bf16(a, wqkv, bqkv, qk, ops.EPI_BF16_SPLITT, out_t=vt, n_split=2 * C)
-    ops.attn_fwd(q, k, vt, oa, L, L, H)
+    ops.attn_fwd(q, k, vt, oa, L, L, H, q_prescaled=True)
     ops.gemm_bf16(oa, wo, b2, xs, ops.EPI_RESID, gate=tab[:, 2], gate_stride=6 * C, row_idx=ridx)
     ops.adaln_modulate(xs, tab[:, 1], tab[:, 0], 6 * C, ridx, True, h, 0)
     ops.gemm_bf16(h, w1, b1, ff, ops.EPI_BF16_GELU)
