@@ -45,7 +45,7 @@ def flops_fwd_5b(L, C=3072, ffn=14336, n=30, Lc=512, cin=48, cout=48):
     return n * blk + 2 * L * (cin * 4) * C + 2 * 512 * (4096 * C + C * C) + 2 * L * (256 * C + C * C + 6 * C * C) + 2 * L * C * 4 * cout
 
 
-PMC_FILES = ("r2_pmc_dominant_kernels.csv", "r1_pmc_dominant_kernels.csv")
+PMC_FILES = ("r2_pmc_traffic_v3.csv", "r2_pmc_dominant_kernels.csv", "r1_pmc_dominant_kernels.csv")
 # only kernels the PMC workload (tools/pmc_probe.py) launches at ONE shape: its gemm256_kernel<3> rows average the o-projection and
 # ffn.2 launches, so the residual-epilogue GEMMs carry no per-launch traffic figure
 PMC_KERNEL_OF_GROUP = {"attn_self": ("attn_fwd_kernel_v7", "attn_combine_kernel"), "gemm_ffn0": ("gemm256_kernel<1", "gemm128_kernel<1"),
