@@ -1,3 +1,7 @@
+#!/bin/bash
+# The measurement set a round ends with (one gpurun call, ~2 min of box time): the default bench under rocprofv3 --kernel-trace --stats,
+# the FETCH / WRITE PMC passes of tools/pmc_probe.py (counters in their own runs), the full default bench (CPU baselines included) and
+# the 14B workload. Results land in gpurun_out/final/; copy what is to be judged into profiles/.
 export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 mkdir -p $R/gpurun_out/final
