@@ -40,6 +40,7 @@ class DiTEngine:
         self._ws = {}
         self._plan_cache = {}
         self.prof = None   # dict kernel-group -> list of (start, end) HIP event pairs when bench.py profiles the timed steps
+        self.prof_only = None   # set of group names: bracket only these (an event pair costs a few µs of queue time per call; ~330 calls per step)
         # the text / CLIP embeddings and every block's cross-attention K, V^T depend only on the
         # conditioning, not on the latent or the timestep; with cache_context they are computed once per conditioning
         # tensor (same object, same version) instead of once per denoise step. Off by default = the reference's work.
@@ -61,7 +62,7 @@ class DiTEngine:
     def _timed(self, name, fn, *a, **k):
         """run one kernel call; with self.prof set, bracket it with HIP events recorded on the launch stream (torch's current
         stream IS the stream ops.* enqueue on)."""
-        if self.prof is None:
+        if self.prof is None or (self.prof_only is not None and name not in self.prof_only):
             return fn(*a, **k)
         ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
         ev[0].record()
