@@ -4,6 +4,26 @@
 
 using namespace gemm_core;
 
+namespace {
+// side stream + fork / join events of the row-split launches (YUME_GEMM_SPLIT_STREAMS=1), one set per device, created on first use
+struct SideStream { hipStream_t s; hipEvent_t fork, join; };
+SideStream* side_stream() {
+    static const bool on = [] { const char* v = getenv("YUME_GEMM_SPLIT_STREAMS"); return v && atoi(v) != 0; }();
+    if (!on) return nullptr;
+    static SideStream per_dev[16];
+    static bool made[16] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+    if (!made[dev]) {
+        SideStream& x = per_dev[dev];
+        if (hipStreamCreateWithFlags(&x.s, hipStreamNonBlocking) != hipSuccess) return nullptr;
+        if (hipEventCreateWithFlags(&x.fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&x.join, hipEventDisableTiming) != hipSuccess) return nullptr;
+        made[dev] = true;
+    }
+    return &per_dev[dev];
+}
+}  // namespace
+
 extern "C" int yume_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, int64_t M,
                               int64_t N, int64_t K, int epi, void* out, int64_t ldo, const float* gate,
                               int64_t gate_stride, const int32_t* row_idx, void* outT, int64_t ldt, int64_t n_split,
@@ -30,14 +50,35 @@ extern "C" int yume_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t
         const int64_t tn = (N + 255) / 256, tm = (M + 255) / 256, T = tm * tn, R = T % 256, full = T - R;
         const int64_t m_main = full / tn, M_main = m_main * 256, rem = M - M_main;
         if (R > 0 && R <= 96 && full >= 256 && m_main >= 1 && rem > 0 && rem <= 1024) {
+            const int64_t osz = (epi == YUME_EPI_F32 || epi == YUME_EPI_RESID) ? 4 : 2;
+            auto remainder = [&](void* s2) {
+                return yume_gemm_bf16(reinterpret_cast<const unsigned short*>(A) + M_main * lda, lda, W, ldw, bias, rem, N, K, epi,
+                                      reinterpret_cast<char*>(out) + M_main * ldo * osz, ldo, gate, gate_stride,
+                                      row_idx ? row_idx + M_main : nullptr,
+                                      outT ? reinterpret_cast<unsigned short*>(outT) + M_main : nullptr, ldt, n_split, 1, s2);
+            };
+            // The remainder launch (a few hundred rows on the 128x128 kernel) fills ~a third of the CUs for as long as a whole round of the
+            // main launch takes; the two touch disjoint output rows. YUME_GEMM_SPLIT_STREAMS=1: it goes to a side stream first (fork / join
+            // by events, graph-capturable) so that its workgroups and the main launch's share the chip instead of running back to back.
+            SideStream* ss = side_stream();
+            if (ss) {
+                hipStream_t st = (hipStream_t)stream;
+                if (hipEventRecord(ss->fork, st) != hipSuccess || hipStreamWaitEvent(ss->s, ss->fork, 0) != hipSuccess) {
+                    yume_set_error("gemm_bf16: side stream fork failed");
+                    return YUME_ELAUNCH;
+                }
+                int rc = remainder((void*)ss->s);
+                if (rc != YUME_OK) return rc;
+                if (hipEventRecord(ss->join, ss->s) != hipSuccess) { yume_set_error("gemm_bf16: side stream join failed"); return YUME_ELAUNCH; }
+                rc = yume_gemm_bf16(A, lda, W, ldw, bias, M_main, N, K, epi, out, ldo, gate, gate_stride, row_idx, outT, ldt, n_split, 2, stream);
+                if (rc != YUME_OK) return rc;
+                if (hipStreamWaitEvent(st, ss->join, 0) != hipSuccess) { yume_set_error("gemm_bf16: side stream join failed"); return YUME_ELAUNCH; }
+                return YUME_OK;
+            }
             int rc = yume_gemm_bf16(A, lda, W, ldw, bias, M_main, N, K, epi, out, ldo, gate, gate_stride, row_idx, outT, ldt, n_split,
                                     2, stream);
             if (rc != YUME_OK) return rc;
-            const int64_t osz = (epi == YUME_EPI_F32 || epi == YUME_EPI_RESID) ? 4 : 2;
-            return yume_gemm_bf16(reinterpret_cast<const unsigned short*>(A) + M_main * lda, lda, W, ldw, bias, rem, N, K, epi,
-                                  reinterpret_cast<char*>(out) + M_main * ldo * osz, ldo, gate, gate_stride,
-                                  row_idx ? row_idx + M_main : nullptr,
-                                  outT ? reinterpret_cast<unsigned short*>(outT) + M_main : nullptr, ldt, n_split, 1, stream);
+            return remainder(stream);
         }
     }
     PlainA al;
