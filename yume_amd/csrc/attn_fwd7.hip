@@ -12,9 +12,19 @@
 //     the MFMAs of a phase never depend on the VALU work beside them, so dependent-latency chains of the softmax hide
 //     under the matrix pipe; one piece (<= ~6 instructions) of the softmax sits in each MFMA gap, written out by hand
 //     (sm_piece<I>) and pinned with sched_barriers;
-//   * the exponentials are taken against the block's running base (deferred rescale, P < 2^13); no row maximum is reduced
-//     on that path: a partial row sum above 2^13 (inf on the first tile) is what sends a tile to the redo path, which
-//     takes the maximum from S, rescales O and l and rebuilds the tile (first tile; then almost never);
+//   * two bodies. ROBUST (any caller): x = s * c - m as one fma per score, the exponentials taken against the block's running base
+//     (deferred rescale, P < 2^13); no row maximum is reduced on that path: a partial row sum above 2^13 (inf on the first tile) is
+//     what sends a tile to the redo path, which takes the maximum from S, rescales O and l and rebuilds the tile (first tile; then
+//     almost never). BASE-FREE (kernel instantiation <true>, AttnArgs::q_prescaled: the caller's Q already carries softmax scale *
+//     log2(e), folded in before Q's one bf16 rounding): the scores leave the matrix pipe as the exponents, p = exp2(s) with no shift
+//     and no base at all — floating point is scale-invariant (exp2(s - m) and exp2(s) carry the same relative error, m cancels in
+//     O / l), so the per-score fma, the per-tile range vote and its branch do not exist. Its guard is ONE check per workgroup at the
+//     end (row sums finite and not tiny, every O element finite, LDS vote over the four waves): a workgroup that fails it reruns
+//     its key range on the robust body inside the launch (Q^T is still in its AGPRs), so every input has a defined result;
+//   * the LDS-DMA pieces of the steady loop ride INSIDE the score-MFMA statements of gaps 0..7 (`s_add_u32 m0, lbase, literal;
+//     v_mfma; global_load_lds`): the MFMA is the wait state the M0 write needs, and the 32 destinations of a four-tile trip cost
+//     one SGPR instead of 32; the even PV gap's MFMA statement names the NEXT gap's V^T fragment too, so one compiler wait covers
+//     the pair. 5.16 (base-free) / 6.3 (robust) instructions per MFMA gap; tests/test_attn7_isa.py holds the budget;
 //   * O (a[0:127]) and Q^T (a[128:191]) live in AGPRs this file OWNS: they are named literally in inline asm (MFMAs,
 //     v_accvgpr_read/write) and listed as clobbers of every such statement, so hipcc keeps nothing of its own there
 //     (tests/test_attn7_isa.py audits the generated code for that). hipcc's own choice for a 512-register kernel puts

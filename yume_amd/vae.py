@@ -29,6 +29,19 @@ def _ru(a, b):
     return (a + b - 1) // b * b
 
 
+def decode_passes(T, group):
+    """[(first_latent, end_latent, first_chunk)] for a T-frame latent: the reference walks range(T) one frame per decoder call with
+    first_chunk = (i == 0) (vae2_2.py:839-857); here frame 0 alone, then `group` frames per call."""
+    return [(0, 1, True)] + [(i, min(T, i + group), False) for i in range(1, T, group)]
+
+
+def encode_passes(T, group):
+    """[(first_frame, end_frame, first_chunk)] for a T-frame video: the reference's chunks are frame 0, then 4 frames each for
+    i = 1 .. (T-1)//4 (vae2_2.py:802-820; a ragged tail of < 4 frames is never encoded); here `group` of those chunks per call."""
+    nchunk = 1 + (T - 1) // 4
+    return [(0, 1, True)] + [(1 + 4 * (i - 1), 1 + 4 * (min(nchunk, i + group) - 1), False) for i in range(1, nchunk, group)]
+
+
 class _Holder(nn.Module):
     """anonymous container; the tree of these reproduces the reference state_dict key names."""
 
@@ -296,11 +309,8 @@ class VaeEngine:
         x = self._new(T, H // ps, W // ps, cpad)
         V.pack_input(v, ps, None, None, x)
         cache, outs = {}, []
-        nchunk = 1 + (T - 1) // 4                     # the reference's chunks: frame 0, then 4 frames each (a ragged tail is dropped)
-        outs.append(self._encoder_pass(x[:1], cache, True))
-        for i in range(1, nchunk, self.group):
-            j = min(nchunk, i + self.group)
-            outs.append(self._encoder_pass(x[1 + 4 * (i - 1):1 + 4 * (j - 1)], cache, False))
+        for a, b, first in encode_passes(T, self.group):
+            outs.append(self._encoder_pass(x[a:b], cache, first))
         out = torch.cat(outs, dim=0)                                     # [T', h, w, 2z(pad)]
         mu = self._conv1("conv1", out)
         Tl, h, w, _ = mu.shape
@@ -330,9 +340,8 @@ class VaeEngine:
         V.pack_input(zl, 1, self._vec(mul, z), self._vec(add, z), x)
         x = self._conv1("conv2", x)
         cache, outs = {}, []
-        outs.append(self._decoder_pass(x[:1], cache, True))
-        for i in range(1, T, self.group):
-            outs.append(self._decoder_pass(x[i:min(T, i + self.group)], cache, False))
+        for a, b, first in decode_passes(T, self.group):
+            outs.append(self._decoder_pass(x[a:b], cache, first))
         out = torch.cat(outs, dim=0)                                     # [T_out, H/ps, W/ps, in_ch(pad)]
         To, Ho, Wo, _ = out.shape
         cv = cfg["in_ch"]
