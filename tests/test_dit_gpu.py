@@ -204,6 +204,34 @@ def test_context_cache_is_bit_identical(name):
     assert not torch.equal(want3, want2)
 
 
+@pytest.mark.parametrize("name", ["dit_wan23_packed_f13", "dit_wan_packed_f13"])
+def test_q_prescale_switch_computes_the_same_model(name):
+    """The engine folds softmax scale * log2(e) into the q RMSNorm weight and tells the attention kernel so (YUME_ATTN_Q_PRESCALED);
+    engine.q_prescale = False keeps the scale inside the kernel. Same model, one bf16 rounding of q placed differently: both meet the
+    reference golden tolerance and agree with each other far inside it; the switch re-packs the weights."""
+    fx = load_golden(name)
+    fam = fx["family"]
+    m = build_model(fam, fx["cfg"], synth.make_dit_state_dict(fx["cfg"], fam, fx["seed"]))
+    inp = {k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in fx["inputs"].items()}
+
+    def run():
+        if fam == "wan23":
+            return m([inp["x"]], t=fx["t"].to(DEV), context=[inp["context"]], seq_len=fx["seq_len"], latent_frame_zero=fx["lfz"], flag=True)[0].clone()
+        return m([inp["x"]], t=fx["t"].to(DEV), context=[inp["context"]], seq_len=fx["seq_len"], clip_fea=inp["clip_fea"], y=[inp["y"]],
+                 rand_num_img=0.6, latent_frame_zero=fx["lfz"])[0].clone()
+
+    assert m.engine.q_prescale
+    on = run()
+    m.engine.q_prescale = False
+    off = run()
+    m.engine.q_prescale = True
+    assert torch.equal(run(), on)
+    want = fx["out"].to(DEV).float() if torch.is_tensor(fx.get("out")) else None
+    assert rel_l2(on.float().cpu(), off.float().cpu()) < 5e-3
+    if want is not None:
+        assert rel_l2(on.float().cpu(), want.cpu()) < 1.5e-2 and rel_l2(off.float().cpu(), want.cpu()) < 1.5e-2
+
+
 def test_prompt_length_edge_cases():
     """Empty prompt (the reference pads [0, text_dim] to text_len zero rows, model.py:816-821), a single token, exactly
     text_len tokens — against the oracle; one token more than text_len is an error."""
