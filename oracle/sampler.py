@@ -5,6 +5,10 @@ own variable flow so it is an independent check of yume_amd/sampling.py:
   euler_14b   fastvideo/sample/sample.py:745-790       (CFG 5.0, history re-noised with sigma_{i+1})
   tts         fastvideo/sample/sample_tts.py:694-868   (SDE eta 0.3, time travel step 2 / interval 2 / repeat 1)
 
+PINNED: the scripts cannot be imported, but their loops can be cut out of the script text and executed — oracle/ref_scripts.py does
+that; tests/test_sampling.py holds this restatement BIT-IDENTICAL to the scripts' own loops (live in the build container, and through
+tests/golden/sampler_scripts.pt, written by oracle/make_golden_sampler.py, anywhere else), including the order and number of model calls.
+
 `transformer(latent, sigma_index, which)` stands for the model call (which in {"cond","uncond"}) and returns the velocity
 for the whole latent; `randn(shape)` stands for torch.randn_like so tests can replay the same noise.
 """

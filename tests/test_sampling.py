@@ -82,3 +82,86 @@ def test_sde_time_travel(S, cfg, renoise):
     assert calls["n"] == sampling.tts_forward_count(S)
     if S == 50:
         assert calls["n"] == 74
+
+
+# ---- pinned to the reference's sampling SCRIPTS: their own loops, cut out of the script text and executed (oracle/ref_scripts.py) ----
+from oracle import ref_scripts  # noqa: E402
+
+GOLD = __import__("os").path.join(ROOT, "tests", "golden", "sampler_scripts.pt")
+
+
+def _script_inputs(fx, dtype):
+    c = ref_scripts.script_case(fx["seed_case"], dtype)
+    return c, ref_scripts.script_field(fx["seed_field"], c["C"]), c["model_input"], c["noise"], fx["lfz"]
+
+
+def _replay(seed, dtype):
+    g = torch.Generator().manual_seed(seed)
+    return lambda shape: torch.randn(shape, generator=g, dtype=dtype)
+
+
+@pytest.mark.skipif(not ref_scripts.available(), reason="needs the reference tree (build container only)")
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+def test_oracle_sampler_is_bit_identical_to_the_reference_scripts_live(dtype):
+    """oracle/sampler.py against sample_tts.py / sample.py / sample_5b.py's OWN loops executed here: same bits, same number of model
+    calls in the same order, and the 5B script's per-token timestep vector is zeros on the history tokens, 1000*sigma_i behind them."""
+    fx = torch.load(GOLD, weights_only=False)
+    c, f, mi, noise, lfz = _script_inputs(fx, dtype)
+    sig3 = list(osamp.get_sampling_sigmas(50, 3.0))
+    for sde in (True, False):
+        ref, draws, calls, span = ref_scripts.run_tts(f, noise.clone(), noise, mi, sig3, lfz, sde=sde, seed=fx["seed_noise"])
+        seen = []
+        got = osamp.tts(lambda l, i, w: (seen.append((i, w)), f(l, i, w))[1], noise.clone(), mi, noise, sig3, lfz,
+                        _replay(fx["seed_noise"], dtype), sde=sde)
+        assert torch.equal(got, ref) and seen == calls and len(calls) == 148 and len(draws) == (74 if sde else 0)
+    for n in (50, 6):
+        sig = list(osamp.get_sampling_sigmas(n, 3.0))
+        ref, calls, _ = ref_scripts.run_euler_14b(f, noise.clone(), noise, mi, sig, lfz)
+        assert torch.equal(osamp.euler_14b(f, noise.clone(), mi, noise, sig, lfz), ref) and len(calls) == 2 * n
+        sig = list(osamp.get_sampling_sigmas(n, 7.0))
+        lat0 = torch.cat([mi[:, :-lfz], noise[:, -lfz:]], dim=1)
+        n0 = (c["F"] - lfz) * (c["H"] // 2) * (c["W"] // 2)
+        seq_len = c["F"] * (c["H"] // 2) * (c["W"] // 2) + 5
+        ref, tvecs, calls, _ = ref_scripts.run_euler_5b(f, lat0.clone(), mi, sig, lfz, seq_len)
+        assert torch.equal(osamp.euler_5b(f, lat0.clone(), mi, sig, lfz), ref) and len(calls) == n
+        for i, t in enumerate(tvecs):
+            want = torch.cat([torch.zeros(n0, dtype=torch.float64), torch.ones(seq_len - n0, dtype=torch.float64) * (sig[i] * 1000)])
+            assert t.shape == (1, seq_len) and t.dtype == torch.float64 and torch.equal(t[0], want)
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+def test_oracle_and_host_loops_match_the_reference_script_fixture(dtype):
+    """the same check from the committed fixture (oracle/make_golden_sampler.py ran the scripts' loops in the build container), plus the
+    product's host loops (yume_amd/sampling.py) against the scripts' results."""
+    fx = torch.load(GOLD, weights_only=False)
+    res = fx["cases"][str(dtype).split(".")[-1]]
+    c, f, mi, noise, lfz = _script_inputs(fx, dtype)
+    tol = dict(rtol=0, atol=1e-12) if dtype == torch.float64 else dict(rtol=0, atol=2e-5)
+    sig3 = list(osamp.get_sampling_sigmas(50, 3.0))
+    vel = lambda lat, i: f(lat, i, "uncond") + 5.0 * (f(lat, i, "cond") - f(lat, i, "uncond"))
+    hist3 = sampling.renoised_history(mi[:, :-lfz], noise[:, :-lfz], sig3)
+    for key, sde in (("tts_50", True), ("tts_50_ode", False)):
+        want = res[key]["latent"]
+        assert res[key]["n_calls"] == 148 and res[key]["n_draws"] == (74 if sde else 0)
+        assert torch.equal(osamp.tts(f, noise.clone(), mi, noise, sig3, lfz, _replay(fx["seed_noise"], dtype), sde=sde), want)
+        got = sampling.sde_tts_chunk(vel, noise.clone(), sig3, lfz, hist3, sde=sde, generator=torch.Generator().manual_seed(fx["seed_noise"]))
+        assert torch.allclose(got, want, **tol), (got - want).abs().max()
+    for n in (50, 6):
+        sig = list(osamp.get_sampling_sigmas(n, 3.0))
+        want = res[f"euler14b_{n}"]["latent"]
+        assert torch.equal(osamp.euler_14b(f, noise.clone(), mi, noise, sig, lfz), want)
+        got = sampling.ode_chunk(vel, noise.clone(), sig, lfz, sampling.renoised_history(mi[:, :-lfz], noise[:, :-lfz], sig))
+        assert torch.allclose(got, want, **tol)
+        sig = list(osamp.get_sampling_sigmas(n, 7.0))
+        want = res[f"euler5b_{n}"]["latent"]
+        lat0 = torch.cat([mi[:, :-lfz], noise[:, -lfz:]], dim=1)
+        assert torch.equal(osamp.euler_5b(f, lat0.clone(), mi, sig, lfz), want)
+        got = sampling.ode_chunk(lambda lat, i: f(lat, i, "cond"), lat0.clone(), sig, lfz, sampling.clean_history(mi[:, :-lfz]))
+        assert torch.allclose(got, want, **tol)
+        # the script's per-token timestep vectors: what make_velocity_5b builds (0 on history tokens, 1000 * sigma_i on the rest, float64)
+        t = res[f"euler5b_{n}"]["t"]
+        n0 = (c["F"] - lfz) * (c["H"] // 2) * (c["W"] // 2)
+        assert t.dtype == torch.float64 and t.shape == (n, 1, res[f"euler5b_{n}"]["seq_len"])
+        for i in range(n):
+            assert torch.equal(t[i, 0, :n0], torch.zeros(n0, dtype=torch.float64))
+            assert torch.equal(t[i, 0, n0:], torch.ones(t.shape[2] - n0, dtype=torch.float64) * (sig[i] * 1000.0))
