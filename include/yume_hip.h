@@ -36,7 +36,7 @@ extern "C" {
 /* ---- library info ------------------------------------------------------------------- */
 const char* yume_last_error(void);
 /* ABI version of this header; bumped on any signature change (yume_amd/_lib.py refuses a library that reports another one). */
-#define YUME_ABI_VERSION 4
+#define YUME_ABI_VERSION 5
 int yume_abi_version(void);
 /* name of the gfx target the kernels were compiled for ("gfx950"). */
 const char* yume_target_arch(void);
@@ -290,6 +290,9 @@ int yume_vae_unpack_output(const void* x, int64_t ldx, int64_t T, int64_t H, int
  * video: fp32 [C, T, H, W] (C <= 4, T*H*W % 4 == 0) -> out: uint8 [T, H, W, C]. Bit-exact (fp32, round half to even).
  */
 int yume_frames_u8(const float* video, int64_t C, int64_t T, int64_t H, int64_t W, void* out, void* stream);
+/* The web app's own variant of the same step (webapp_single_gpu.py:117-121 `_postprocess_video`, in-tree code):
+ *   ((video.clamp(-1, 1) + 1) / 2 * 255).byte()  — the same affine map, but TRUNCATED to uint8 instead of rounded. Same layouts. */
+int yume_frames_u8_trunc(const float* video, int64_t C, int64_t T, int64_t H, int64_t W, void* out, void* stream);
 
 /* ======================================================================================================
  * umT5-XXL text encoder (the step before the path; wan/modules/t5.py:440-513 T5EncoderModel,

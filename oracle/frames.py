@@ -19,3 +19,12 @@ def frames_u8(video):
     den = (video.float() * 0.5 + 0.5).clamp(0, 1)
     arr = den.permute(1, 2, 3, 0).contiguous().numpy()
     return (arr * 255).round().astype("uint8")
+
+
+def frames_u8_webapp(video):
+    """the web app's own conversion (webapp_single_gpu.py:117-121, IN-TREE reference code): ((v.clamp(-1,1) + 1) / 2 * 255).byte() — the cast
+    truncates. Unlike the diffusers variant above this one is PINNED: tests/test_frames.py runs the reference function itself
+    (oracle/ref_scripts.py::run_webapp_postprocess) against it, and tests/golden/frames_webapp.pt holds its output for the GPU box.
+    video: torch fp32 [C,T,H,W] -> numpy uint8 [T,H,W,C]."""
+    v = video.float().clamp(-1, 1).add(1).div(2)
+    return (v * 255).byte().permute(1, 2, 3, 0).contiguous().numpy()

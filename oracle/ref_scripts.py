@@ -142,3 +142,34 @@ def script_case(seed, dtype, C=6, F=7, H=4, W=6):
     g = torch.Generator().manual_seed(seed)
     mk = lambda: torch.randn(C, F, H, W, generator=g, dtype=torch.float64).to(dtype)
     return dict(model_input=mk(), noise=mk(), C=C, F=F, H=H, W=W)
+
+
+# ---- the web app's frame conversion (webapp_single_gpu.py:117-121) ----------------------------------------------------------------------
+def run_webapp_postprocess(video):
+    """executes the reference's `_postprocess_video(video, fps, out_path)` itself (cut out of webapp_single_gpu.py, which cannot be
+    imported: gradio, the model stack and CUDA at import) with `export_to_video` replaced by a recorder.
+    video: fp32 [C,F,H,W] -> numpy uint8 [F,H,W,C] (the frames it would have encoded)."""
+    import numpy as np
+    from PIL import Image
+    src = open(os.path.join(REF, "webapp_single_gpu.py")).read().split("\n")
+    h = next(i for i, l in enumerate(src) if l.startswith("def _postprocess_video("))
+    e = h + 1
+    while e < len(src) and (src[e].strip() == "" or src[e].startswith((" ", "\t"))):
+        e += 1
+    got = {}
+    ns = dict(torch=torch, np=np, Image=Image, export_to_video=lambda frames, out_path, fps=None: got.update(frames=frames, fps=fps))
+    exec(compile("\n".join(src[h:e]), "webapp_single_gpu.py[%d:%d]" % (h + 1, e), "exec"), ns)      # (the decorator line above it is not needed)
+    ns["_postprocess_video"](video, 16, "unused.mp4")
+    return np.stack([np.asarray(f) for f in got["frames"]])
+
+
+def webapp_case(seed=3, shape=(3, 5, 16, 24)):
+    """seeded video with every k/255 and k/255 +- one ulp boundary of the truncating conversion among its samples, values outside [-1, 1]"""
+    g = torch.Generator().manual_seed(seed)
+    v = torch.randn(shape, generator=g) * 0.8
+    flat = v.view(-1)
+    k = torch.arange(256, dtype=torch.float64)
+    edge = ((k / 255) * 2 - 1).float()
+    pts = torch.cat([edge, torch.nextafter(edge, torch.tensor(2.0)), torch.nextafter(edge, torch.tensor(-2.0)), torch.tensor([-1.5, 1.5, -1.0, 1.0, 0.0])])
+    flat[:pts.numel()] = pts
+    return v

@@ -81,3 +81,46 @@ def test_tiled_decode_overlap_matches_reference_outputs():
     # 5B 720P call shape (webapp_single_gpu.py:830): 80 latent columns, 5 bands of 16 (+2 towards each neighbour)
     assert _tile_spans(80, 5, 2) == [(0, 18), (14, 34), (30, 50), (46, 66), (62, 80)]
     assert _tile_spans(23, 5, 2) == [(0, 7), (3, 12), (8, 17), (13, 21), (17, 23)]
+
+
+# ---- the web app's own conversion (webapp_single_gpu.py:117-121): pinned by executing the reference function itself -------------------
+import os  # noqa: E402
+
+from oracle import ref_scripts  # noqa: E402
+
+WEBAPP_GOLD = os.path.join(ROOT, "tests", "golden", "frames_webapp.pt")
+
+
+def _webapp_fixture():
+    fx = torch.load(WEBAPP_GOLD, weights_only=False)
+    v = ref_scripts.webapp_case()
+    assert tuple(v.shape) == fx["shape"] and abs(float(v.double().sum()) - fx["checksum"]) < 1e-9
+    return v, fx["frames"].numpy()
+
+
+@pytest.mark.skipif(not ref_scripts.available(), reason="needs the reference tree (build container only)")
+def test_webapp_conversion_restated_equals_the_reference_function_live():
+    v = ref_scripts.webapp_case()
+    want = ref_scripts.run_webapp_postprocess(v.clone())
+    assert want.dtype == np.uint8 and want.shape == (v.shape[1], v.shape[2], v.shape[3], v.shape[0])
+    assert np.array_equal(oframes.frames_u8_webapp(v), want)
+    # it is NOT the diffusers conversion: truncation vs round-half-even differ on most samples
+    assert (oframes.frames_u8(v) != want).mean() > 0.3
+
+
+def test_webapp_conversion_fixture():
+    v, want = _webapp_fixture()
+    assert np.array_equal(oframes.frames_u8_webapp(v), want)
+
+
+@pytest.mark.gpu
+def test_frames_u8_trunc_bit_exact_vs_the_webapp_function():
+    from yume_amd import video
+    v, want = _webapp_fixture()
+    got = video.frames_u8(v.cuda(), truncate=True)
+    assert got.dtype == torch.uint8 and np.array_equal(got.cpu().numpy(), want)
+    pil = video.postprocess_video_webapp(v.cuda())
+    assert len(pil) == v.shape[1] and np.array_equal(np.asarray(pil[2]), want[2])
+    g = torch.Generator().manual_seed(1)
+    big = torch.randn(3, 4, 64, 96, generator=g)
+    assert np.array_equal(video.frames_u8(big.cuda(), truncate=True).cpu().numpy(), oframes.frames_u8_webapp(big))

@@ -44,12 +44,13 @@ SIGNATURES = {
     "yume_softmax_rows": [_P, _L, _L, _L, _F, _P, _L, _P],
     "yume_vae_pack_input": [_P, _I, _L, _L, _L, _L, _I, _P, _P, _P, _L, _P],
     "yume_frames_u8": [_P, _L, _L, _L, _L, _P, _P],
+    "yume_frames_u8_trunc": [_P, _L, _L, _L, _L, _P, _P],
     "yume_vae_unpack_output": [_P, _L, _L, _L, _L, _L, _I, _P, _P, _F, _F, _P, _P],
 }
 _RES = {"yume_last_error": c_char_p, "yume_target_arch": c_char_p, "yume_gemm_splitk_workspace_bytes": c_int64, "yume_attn_workspace_bytes": c_int64}
 
 _lib = None
-ABI_VERSION = 4          # must equal YUME_ABI_VERSION in include/yume_hip.h; bumped whenever an argument list changes
+ABI_VERSION = 5          # must equal YUME_ABI_VERSION in include/yume_hip.h; bumped whenever an argument list changes
 
 
 def load():

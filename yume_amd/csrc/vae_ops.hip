@@ -206,7 +206,8 @@ __global__ __launch_bounds__(256) void unpack_output_kernel(const unsigned short
 
 // fp32 [C, T, H, W] in [-1, 1] -> uint8 [T, H, W, C]: one thread = 4 consecutive w of all C channels
 // (C coalesced 16-byte loads, one contiguous 4*C-byte store). HBM-bound: 4 B read + 1 B written per element.
-template <int C>
+// TRUNC: the web app's own conversion (webapp_single_gpu.py:117-121): ((x.clamp(-1, 1) + 1) / 2 * 255).byte() — truncation, no rounding
+template <int C, bool TRUNC>
 __global__ __launch_bounds__(256) void frames_u8_kernel(const float* __restrict__ x, int64_t plane /* T*H*W */, int64_t nquad,
                                                         unsigned char* __restrict__ out) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nquad; i += (int64_t)gridDim.x * blockDim.x) {
@@ -217,9 +218,14 @@ __global__ __launch_bounds__(256) void frames_u8_kernel(const float* __restrict_
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 // diffusers VideoProcessor: denormalize (x * 0.5 + 0.5).clamp(0, 1), then (x * 255).round() -> uint8 (half to even)
-                float f = __fadd_rn(__fmul_rn(v[q], 0.5f), 0.5f);
-                f = fminf(fmaxf(f, 0.f), 1.f);
-                b[q * C + c] = (unsigned char)(int)rintf(__fmul_rn(f, 255.f));
+                if (TRUNC) {
+                    const float f = __fmul_rn(__fadd_rn(fminf(fmaxf(v[q], -1.f), 1.f), 1.f), 0.5f);
+                    b[q * C + c] = (unsigned char)(int)__fmul_rn(f, 255.f);        // (int): toward zero, like Tensor.byte()
+                } else {
+                    float f = __fadd_rn(__fmul_rn(v[q], 0.5f), 0.5f);
+                    f = fminf(fmaxf(f, 0.f), 1.f);
+                    b[q * C + c] = (unsigned char)(int)rintf(__fmul_rn(f, 255.f));
+                }
             }
         }
         unsigned char* dst = out + 4 * C * i;
@@ -367,7 +373,8 @@ extern "C" int yume_vae_unpack_output(const void* x, int64_t ldx, int64_t T, int
     return YUME_OK;
 }
 
-extern "C" int yume_frames_u8(const float* video, int64_t C, int64_t T, int64_t H, int64_t W, void* out, void* stream) {
+template <bool TRUNC>
+static int frames_u8_impl(const float* video, int64_t C, int64_t T, int64_t H, int64_t W, void* out, void* stream) {
     YUME_REQUIRE(video && out, "frames_u8: NULL pointer");
     YUME_REQUIRE(C >= 1 && C <= 4 && T > 0 && H > 0 && W > 0, "frames_u8: bad shape C=%lld T=%lld H=%lld W=%lld", (long long)C, (long long)T, (long long)H, (long long)W);
     const int64_t plane = T * H * W;
@@ -377,13 +384,21 @@ extern "C" int yume_frames_u8(const float* video, int64_t C, int64_t T, int64_t 
     hipStream_t st = (hipStream_t)stream;
     unsigned char* o = (unsigned char*)out;
     switch ((int)C) {
-        case 1: hipLaunchKernelGGL((frames_u8_kernel<1>), dim3(grid_for(nquad)), dim3(256), 0, st, video, plane, nquad, o); break;
-        case 2: hipLaunchKernelGGL((frames_u8_kernel<2>), dim3(grid_for(nquad)), dim3(256), 0, st, video, plane, nquad, o); break;
-        case 3: hipLaunchKernelGGL((frames_u8_kernel<3>), dim3(grid_for(nquad)), dim3(256), 0, st, video, plane, nquad, o); break;
-        default: hipLaunchKernelGGL((frames_u8_kernel<4>), dim3(grid_for(nquad)), dim3(256), 0, st, video, plane, nquad, o); break;
+        case 1: hipLaunchKernelGGL((frames_u8_kernel<1, TRUNC>), dim3(grid_for(nquad)), dim3(256), 0, st, video, plane, nquad, o); break;
+        case 2: hipLaunchKernelGGL((frames_u8_kernel<2, TRUNC>), dim3(grid_for(nquad)), dim3(256), 0, st, video, plane, nquad, o); break;
+        case 3: hipLaunchKernelGGL((frames_u8_kernel<3, TRUNC>), dim3(grid_for(nquad)), dim3(256), 0, st, video, plane, nquad, o); break;
+        default: hipLaunchKernelGGL((frames_u8_kernel<4, TRUNC>), dim3(grid_for(nquad)), dim3(256), 0, st, video, plane, nquad, o); break;
     }
     YUME_CHECK_LAUNCH("frames_u8");
     return YUME_OK;
+}
+
+extern "C" int yume_frames_u8(const float* video, int64_t C, int64_t T, int64_t H, int64_t W, void* out, void* stream) {
+    return frames_u8_impl<false>(video, C, T, H, W, out, stream);
+}
+
+extern "C" int yume_frames_u8_trunc(const float* video, int64_t C, int64_t T, int64_t H, int64_t W, void* out, void* stream) {
+    return frames_u8_impl<true>(video, C, T, H, W, out, stream);
 }
 
 extern "C" int yume_softmax_bias_rows(const float* S, int64_t lds, int64_t strideS, int64_t H, int64_t n, const float* bias,

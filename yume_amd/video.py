@@ -12,8 +12,9 @@ import torch
 from . import _lib
 
 
-def frames_u8(video):
-    """video fp32 [C,T,H,W] (device, contiguous) -> uint8 [T,H,W,C] (device)."""
+def frames_u8(video, truncate=False):
+    """video fp32 [C,T,H,W] (device, contiguous) -> uint8 [T,H,W,C] (device). truncate=False: diffusers' rounding (the sampling scripts);
+    truncate=True: the web app's own `_postprocess_video` (webapp_single_gpu.py:117-121), which casts with .byte()."""
     if not isinstance(video, torch.Tensor) or video.device.type != "cuda":
         raise RuntimeError("yume_amd.video: the video must be a device ('cuda') tensor — this path has no CPU fallback")
     if video.dim() != 4 or video.dtype != torch.float32:
@@ -21,9 +22,18 @@ def frames_u8(video):
     video = video.contiguous()
     C, T, H, W = video.shape
     out = torch.empty((T, H, W, C), dtype=torch.uint8, device=video.device)
-    rc = _lib.load().yume_frames_u8(video.data_ptr(), C, T, H, W, out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    lib = _lib.load()
+    fn = lib.yume_frames_u8_trunc if truncate else lib.yume_frames_u8
+    rc = fn(video.data_ptr(), C, T, H, W, out.data_ptr(), torch.cuda.current_stream().cuda_stream)
     _lib.check(rc, "yume_frames_u8")
     return out
+
+
+def postprocess_video_webapp(video):
+    """The frame conversion of the reference's web app (`_postprocess_video`, webapp_single_gpu.py:117-121, without its mp4 export):
+    video fp32 [C,F,H,W] in [-1,1] on the device -> list of F PIL images; `((v.clamp(-1,1) + 1) / 2 * 255).byte()` runs in HBM."""
+    from PIL import Image
+    return [Image.fromarray(f) for f in frames_u8(video.float(), truncate=True).cpu().numpy()]
 
 
 class VideoProcessor:
