@@ -163,3 +163,47 @@ def ref_clip():
         spec.loader.exec_module(m)
         _cache["clip"] = m
     return _cache["clip"]
+
+
+class _DistWithListAllToAll:
+    """torch.distributed for the reference's wan23/distributed/util.py on the gloo backend (CPU tests): gloo has no list all_to_all, so
+    that ONE call is served by all_to_all_single (same collective: outputs[i] <- what rank i put in its inputs[my rank]); everything else
+    is torch.distributed's."""
+
+    def __getattr__(self, name):
+        import torch.distributed as dist
+        return getattr(dist, name)
+
+    @staticmethod
+    def all_to_all(outputs, inputs, group=None, **kw):
+        import torch.distributed as dist
+        send = torch.stack([u.contiguous() for u in inputs])
+        recv = torch.empty_like(send)
+        dist.all_to_all_single(recv.view(torch.uint8), send.view(torch.uint8), group=group)
+        for o, r in zip(outputs, recv):
+            o.copy_(r)
+
+
+def ref_ulysses():
+    """the reference's wan23/distributed/ulysses.py (`distributed_attention`) with its flash_attention bound to the exact-softmax stand-in
+    and its util's `dist` to the shim above. Needs an initialised process group when called."""
+    assert available(), "reference tree not present"
+    key = ("ulysses",)
+    if key not in _cache:
+        _stub_diffusers()
+        _import_pkg("wan23", ["attention"])
+        sub = types.ModuleType("wan23.distributed")
+        sub.__path__ = [os.path.join(REF_ROOT, "wan23", "distributed")]
+        sys.modules["wan23.distributed"] = sub
+        mods = {}
+        for f in ("util", "ulysses"):
+            name = "wan23.distributed." + f
+            spec = importlib.util.spec_from_file_location(name, os.path.join(REF_ROOT, "wan23", "distributed", f + ".py"))
+            m = importlib.util.module_from_spec(spec)
+            sys.modules[name] = m
+            spec.loader.exec_module(m)
+            mods[f] = m
+        mods["util"].dist = _DistWithListAllToAll()
+        mods["ulysses"].flash_attention = sdpa_standin
+        _cache[key] = mods["ulysses"]
+    return _cache[key]

@@ -85,3 +85,35 @@ def test_world_one_is_identity():
             SequenceParallel.check_heads(type("S", (), {"world": 4})(), 6)
     finally:
         dist.destroy_process_group()
+
+
+# ---- against the reference's own distributed_attention (wan23/distributed/ulysses.py:9-47), executed under gloo ----------------------
+def _ref_worker(rank, world, port, L, H):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import ref_import
+    from yume_amd.ulysses import SequenceParallel
+    ref = ref_import.ref_ulysses()
+    sp = SequenceParallel()
+    q, k, v, Lp = _global(L, H, world)
+    assert world * Lp == L, "the reference chunks the sequence evenly: choose L = world * multiple of 8"
+    C = H * D
+    rows = slice(rank * Lp, (rank + 1) * Lp)
+    # the reference: token-major [B, L/P, N, D] shards in, [B, L/P, N, D] out (4 list all-to-alls + flash_attention in the middle)
+    shard = lambda t: t[rows].float().view(1, Lp, H, D)
+    want = ref.distributed_attention(shard(q), shard(k), shard(v), seq_lens=torch.tensor([L])).reshape(Lp, C)
+    # here: one packed exchange in, the same attention on the rank's heads, one exchange out
+    qf, kf, vtf = sp.exchange_qkv(torch.cat([q[rows], k[rows]], dim=1).contiguous(), v[rows].t().contiguous(), C)
+    got = sp.exchange_out(_attention(qf, kf, vtf.t(), H // world, L).contiguous())
+    assert got.shape == want.shape and torch.allclose(got, want, rtol=0, atol=2e-6), (got - want).abs().max()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,L,H", [(2, 48, 4), (4, 64, 8)])
+def test_exchange_matches_the_references_distributed_attention(world, L, H):
+    from oracle import ref_import
+    if not ref_import.available():
+        pytest.skip("needs the reference tree (build container only)")
+    mp.spawn(_ref_worker, args=(world, _free_port(), L, H), nprocs=world, join=True)
