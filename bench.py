@@ -198,6 +198,11 @@ def kernel_rooflines(prof, steps, ms_per_step, L, cfg, Lc=512):
     return out
 
 
+def _coll_dev(dev):
+    """device of the small timing / checksum collectives: the GPU under RCCL, the host under gloo (YUME_BENCH_SHARE_GPU test mode)."""
+    return torch.device("cpu") if dist.is_initialized() and dist.get_backend() == "gloo" else torch.device(dev)
+
+
 def _timed(fn, world):
     """barrier + synchronize on both sides, max over ranks (the driver's contract)."""
     torch.cuda.synchronize()
@@ -210,7 +215,7 @@ def _timed(fn, world):
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
+    dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=_coll_dev("cuda"))
     if world > 1:
         dist.all_reduce(dt, op=dist.ReduceOp.MAX)
     return r, float(dt.item())
@@ -365,7 +370,7 @@ def bench_14b(args, rank, world, dev):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     assert torch.isfinite(latent).all()
-    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    tmax = torch.tensor([dt], dtype=torch.float64, device=_coll_dev(dev))
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     tmax = float(tmax.item())
@@ -381,6 +386,26 @@ def bench_14b(args, rank, world, dev):
                           "peak_mem_gb": torch.cuda.max_memory_allocated() / 1e9}), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def _self_launch(args, share):
+    """`python bench.py --gpus N` outside torchrun: become the N-rank job (one process per GPU over RCCL, the launch the
+    reference's scripts use — torchrun --nproc_per_node N fastvideo/sample/sample_5b.py, scripts/inference/sample_5b.sh; one
+    process per GPU at sample_5b.py:1124-1134). Refuses by name when the node has fewer than N GPUs."""
+    import socket
+    n = args.gpus
+    have = torch.cuda.device_count()
+    if have < n and not share:
+        sys.exit(f"bench.py: --gpus {n} requested but this node shows {have} GPU(s): refusing to run {n} ranks on fewer devices "
+                 "(a 1-rank run would print n_gpus: 1, not what was asked)")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stdout.flush()
+    os.execv(sys.executable, cmd)
 
 
 def main():
@@ -400,14 +425,25 @@ def main():
     ap.add_argument("--chunks", type=int, default=8, help="longvideo only: number of 2 s chunks (BASELINE: 8)")
     args = ap.parse_args()
 
+    share = os.environ.get("YUME_BENCH_SHARE_GPU", "0") == "1"   # test mode only: every rank on cuda:0, gloo instead of RCCL
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        _self_launch(args, share)                                 # does not return
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    local = 0 if share else int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks; pass --gpus {world} "
+                 f"(or run `python bench.py --gpus {args.gpus}` alone: it launches its own ranks)")
+    if not share and torch.cuda.device_count() < world:
+        sys.exit(f"bench.py: {world} ranks need {world} GPUs, this node shows {torch.cuda.device_count()}")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)   # RCCL over xGMI
+        if share:
+            dist.init_process_group("gloo")              # collectives staged through the host (yume_amd.distributed)
+        else:
+            dist.init_process_group("nccl", device_id=dev)   # RCCL over xGMI
 
     import __graft_entry__ as ge
     if rank == 0:
@@ -493,7 +529,7 @@ def main():
         del lat_x
     assert torch.isfinite(latent).all(), "non-finite latents"
     # results of every chain are gathered at chunk end (the only other collective of the run)
-    checks = ydist.gather_scalars(float(latent[:, -lfz:].double().abs().mean()), device=dev)
+    checks = ydist.gather_scalars(float(latent[:, -lfz:].double().abs().mean()), device=_coll_dev(dev))
 
     # SURVEY §8(f).1 (step-invariant conditioning cached across steps): reported beside the headline, never as `value`
     cached_ms = None
@@ -513,7 +549,7 @@ def main():
     if not args.no_vae and rank == 0:
         vae_res = vae_decode_rate(dev, latent[:, -lfz:].float())
 
-    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    tmax = torch.tensor([dt], dtype=torch.float64, device=_coll_dev(dev))
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     tmax = float(tmax.item())

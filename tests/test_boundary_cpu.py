@@ -123,3 +123,59 @@ def test_level0_patch_grid_refuses_odd_sizes():
     with pytest.raises(ValueError, match="must be even"):
         framepack.pack_plan(13, 45, 80, 8)
     assert framepack.pack_plan(13, 44, 80, 8).seq_len == 9460
+
+
+@pytest.mark.parametrize("family", ["wan23", "wan"])
+def test_model_pickles_and_rebinds_its_blocks(family):
+    """torch.save(model) / spawn workers pickle the module: the blocks' owner reference is not part of the state (a weakref cannot be
+    pickled) and the unpickled model re-binds its blocks; the device engine never travels."""
+    import io
+    import pickle
+    if family == "wan23":
+        from yume_amd.wan23.modules.model import WanModel
+    else:
+        from yume_amd.wan.modules.model import WanModel
+    m = WanModel(**synth.tiny_cfg(family))
+    synth.randomize_module_(m, seed=3)
+    m2 = pickle.loads(pickle.dumps(m))
+    assert m2._engine is None and all(b._owner() is m2 and b._index == i for i, b in enumerate(m2.blocks))
+    for (k, a), (k2, b) in zip(m.state_dict().items(), m2.state_dict().items()):
+        assert k == k2 and torch.equal(a, b)
+    buf = io.BytesIO()
+    torch.save(m, buf)
+    buf.seek(0)
+    m3 = torch.load(buf, weights_only=False)
+    assert m3.blocks[-1]._owner() is m3 and hasattr(m3, "_forward_hooks")
+    assert deepcopy(m).blocks[0]._owner() is not m
+    assert pickle.loads(pickle.dumps(m.blocks[0]))._owner is None      # a block on its own has no owner
+
+
+def test_clean_prompt_matches_the_reference_cleaners():
+    """yume_amd.t5.clean_prompt against the reference's own basic_clean + whitespace_clean (wan/modules/tokenizers.py:12-22), executed
+    from the reference file with ftfy.fix_text stubbed to the identity on BOTH sides (ftfy is not in this image; requirements.txt
+    declares it) — the html / whitespace arithmetic is what is compared."""
+    ref = "/root/reference/wan/modules/tokenizers.py"
+    if not os.path.exists(ref):
+        pytest.skip("reference tree not present")
+    from yume_amd.t5 import clean_prompt
+    src = open(ref).read()
+    ns = {}
+    stub = types.ModuleType("ftfy")
+    stub.fix_text = lambda t: t
+    saved = sys.modules.get("ftfy")
+    sys.modules["ftfy"] = stub
+    try:
+        head = src.split("class HuggingfaceTokenizer")[0].replace("from transformers import AutoTokenizer", "")
+        exec(compile(head, ref, "exec"), ns)
+    finally:
+        if saved is None:
+            del sys.modules["ftfy"]
+        else:
+            sys.modules["ftfy"] = saved
+    for t in ["  a  cat &amp;amp; a\tdog \n\n walk  ", "&lt;b&gt;bold&lt;/b&gt;", "", "  ", "x", "café   au   lait", "a&nbsp;b"]:
+        assert clean_prompt(t, fix_text=lambda s: s) == ns["whitespace_clean"](ns["basic_clean"](t)), repr(t)
+    try:
+        import ftfy  # noqa: F401
+    except ImportError:
+        with pytest.raises(RuntimeError, match="ftfy"):
+            clean_prompt("x")

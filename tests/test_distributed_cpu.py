@@ -94,3 +94,15 @@ def test_single_process_helpers_are_noops():
     assert torch.equal(D.all_gather_results(t), t.unsqueeze(0))
     assert D.gather_scalars(3.0) == [3.0]
     assert D.shard_indices(5, 0, 1) == [0, 1, 2, 3, 4]
+
+
+def test_bench_gpus_n_without_enough_gpus_refuses_by_name():
+    """bench.py --gpus 2 outside torchrun launches its own ranks (tests/test_distributed_gpu.py); on a node with fewer than 2 GPUs
+    (this container: none) it must refuse by name instead of silently running one rank and printing n_gpus: 1."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "YUME_BENCH_SHARE_GPU")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("multi-GPU node")
+    assert r.returncode != 0
+    assert "--gpus 2 requested but this node shows" in r.stderr and "{" not in r.stdout

@@ -55,3 +55,44 @@ def test_two_rank_rccl_replication_and_independent_chains(tmp_path):
     mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     a, b = torch.load(tmp_path / "r0.pt"), torch.load(tmp_path / "r1.pt")
     assert torch.equal(a, b)                                     # both ranks gathered the same pair of results
+
+
+def _run_bench(extra_args, env_extra, timeout=900):
+    import json
+    import subprocess
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", **env_extra)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + extra_args, capture_output=True, text=True, timeout=timeout, env=env, cwd=ROOT)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    return r, (json.loads(lines[-1]) if lines else None)
+
+
+def test_bench_gpus_2_launches_two_ranks_itself():
+    """`python bench.py --gpus 2` without torchrun's env must BECOME the 2-rank job (the reference launches one process per GPU:
+    fastvideo/sample/sample_5b.py:1124-1134, index = (step-1)*world + rank at :782-785). The single-GPU test box has one device, so the two
+    ranks share cuda:0 and talk gloo (YUME_BENCH_SHARE_GPU=1, test mode); everything else is bench's own N > 1 control flow: per-rank
+    chains, weight replication from rank 0, barrier-bracketed timing, max over ranks, one JSON line from rank 0."""
+    r, line = _run_bench(["--gpus", "2", "--layers", "1", "--steps", "2", "--warmup", "1", "--no-vae", "--no-cpu-baseline"],
+                         {"YUME_BENCH_SHARE_GPU": "1"})
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert line is not None, r.stdout[-2000:]
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak"
+    assert len(line["chain_checksums"]) == 2 and line["chain_checksums"][0] != line["chain_checksums"][1]
+    assert line["weight_broadcast_collectives"] > 0
+    assert line["config"]["parallelism"].startswith("dp2")
+    assert line["value"] > 0 and abs(line["value"] - 2 * 2 / (line["ms_per_step"] * 2e-3)) < 1e-6 * line["value"]
+
+
+@pytest.mark.skipif(torch.cuda.device_count() >= 2, reason="a multi-GPU box runs it for real")
+def test_bench_gpus_2_on_one_gpu_refuses_by_name():
+    r, line = _run_bench(["--gpus", "2", "--layers", "1", "--steps", "1", "--warmup", "1", "--no-vae", "--no-cpu-baseline"], {}, timeout=300)
+    assert r.returncode != 0 and line is None
+    assert "--gpus 2 requested but this node shows 1 GPU" in r.stderr
+
+
+def test_bench_gpus_mismatch_with_launcher_world_size_is_an_error():
+    import subprocess
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr

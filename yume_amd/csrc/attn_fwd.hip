@@ -970,7 +970,22 @@ __global__ __launch_bounds__(256) void attn_combine_kernel(const float* __restri
 // whose pieces are dispatched behind the whole blocks (same launch) and merged by attn_combine_kernel. The plan minimises the
 // makespan of that in-order dispatch under a simple cost model (a piece = 1/splits of a block + a fixed prologue share).
 struct Plan7 { int64_t tail_qb; int splits; };
+static Plan7 attn7_plan_search(int64_t Lq, int64_t Lk, int64_t H);
+// the search below (~37 makespan simulations with a 32-way min-scan per workgroup) is a pure function of the launch shape and
+// runs on the host inside every yume_attn_fwd_ws call (30-40 times per denoise step): memoised per calling thread
 static Plan7 attn7_plan(int64_t Lq, int64_t Lk, int64_t H) {
+    struct Entry { int64_t Lq, Lk, H; Plan7 pl; };
+    static thread_local Entry memo[8];
+    static thread_local int used = 0, next = 0;
+    for (int i = 0; i < used; ++i)
+        if (memo[i].Lq == Lq && memo[i].Lk == Lk && memo[i].H == H) return memo[i].pl;
+    const Plan7 pl = attn7_plan_search(Lq, Lk, H);
+    memo[next] = Entry{Lq, Lk, H, pl};
+    next = (next + 1) & 7;
+    used = used < 8 ? used + 1 : 8;
+    return pl;
+}
+static Plan7 attn7_plan_search(int64_t Lq, int64_t Lk, int64_t H) {
     const int64_t nq = (Lq + QB4 - 1) / QB4, hx = (H + 7) / 8, nt = (Lk + KT - 1) / KT;
     Plan7 best{nq, 1};
     auto makespan = [&](int64_t tail_q, int splits) {

@@ -629,12 +629,14 @@ __device__ __forceinline__ void run_keys(const AttnArgs& p, const Ctx& cx, const
 // FAST pass only: did every row of this wave's block stay inside the range? The row sum has to be finite (an overflowing exponential —
 // a score above 127 — makes it inf) and not tiny (a row whose scores all sit below about -100 loses its small terms to the flush-to-zero
 // of exp2, or sums to 0), and no O^T element may be inf / NaN (0 * x summed over the block is 0 exactly when every x is finite).
+// The bounds leave 2^8 of headroom (row sum < 2^120, |O^T| < 2^120: 0 * (2^8 x) is 0 exactly when |x| < 2^120): up to four key-range
+// pieces of one row pass this check at the same base (m = 0) and attn_combine_kernel adds their l and O without rescaling.
 template <int XO>
 __device__ __forceinline__ bool block_in_range(const Blk& x) {
     const float l_tot = xhalf_sum(x.z.l_run);
     float z = 0.f;
-    for_regs<0, 64>([&](auto r) { z = __builtin_fmaf(agpr_get<XO + decltype(r)::value>(), 0.f, z); });
-    return (l_tot > 0x1p-100f) & (l_tot < 0x1p126f) & (z == 0.f);
+    for_regs<0, 64>([&](auto r) { z = __builtin_fmaf(agpr_get<XO + decltype(r)::value>() * 0x1p8f, 0.f, z); });
+    return (l_tot > 0x1p-100f) & (l_tot < 0x1p120f) & (z == 0.f);
 }
 
 // PRE: Q already carries softmax scale * log2(e) (AttnArgs::q_prescaled; scale_log2 is 1): the FAST pieces run first.

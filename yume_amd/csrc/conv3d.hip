@@ -170,7 +170,7 @@ extern "C" int yume_conv3d_cl(const void* x, const void* cache, int64_t ldc, int
     YUME_REQUIRE((To - 1) * st + (kt - 1) - pt < Tin, "conv3d_cl: temporal extent exceeds the input (To=%lld Tin=%lld)", (long long)To, (long long)Tin);
     const int64_t M = To * Ho * Wo;
     YUME_REQUIRE(M < (1ll << 31), "conv3d_cl: too many output positions");
-    YUME_REQUIRE(((uintptr_t)x % 16) == 0 && ((uintptr_t)W % 16) == 0 && ((uintptr_t)out % 8) == 0 && ((uintptr_t)zero_page % 16) == 0 &&
+    YUME_REQUIRE(((uintptr_t)x % 16) == 0 && ((uintptr_t)W % 16) == 0 && ((uintptr_t)out % 16) == 0 && ((uintptr_t)zero_page % 16) == 0 &&
                  (cache == nullptr || ((uintptr_t)cache % 16) == 0), "conv3d_cl: pointer alignment");
     Problem p;
     p.W = (const unsigned short*)W; p.ldw = ldw;

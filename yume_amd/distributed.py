@@ -54,7 +54,9 @@ def broadcast_module_(module, src=0, bucket_bytes=1 << 30, mode=None):
     by_dtype = {}
     for t in tensors:
         by_dtype.setdefault((t.dtype, t.device), []).append(t)
-    for (dtype, dev), ts in by_dtype.items():
+    host_staged = dist.get_backend() == "gloo"      # gloo moves host memory: device buckets are staged through the host
+    for (dtype, pdev), ts in by_dtype.items():
+        dev = torch.device("cpu") if host_staged else pdev
         cap = max(1, bucket_bytes // ts[0].element_size())
         i = 0
         while i < len(ts):

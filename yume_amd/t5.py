@@ -237,18 +237,21 @@ def umt5_xxl(encoder_only=True, return_tokenizer=False, dtype=torch.float32, dev
     return model.to(dtype=dtype, device=device)
 
 
-def clean_prompt(text):
+def clean_prompt(text, fix_text=None):
     """the `clean='whitespace'` preprocessing of the reference tokenizer wrapper (wan/modules/tokenizers.py:12-22,75-77):
-    ftfy.fix_text, html.unescape twice, strip, runs of whitespace -> one blank. ftfy is required exactly as in the reference:
-    without it mojibake would silently tokenise differently, so its absence is an error, not a fallback."""
+    ftfy.fix_text, html.unescape twice, strip, runs of whitespace -> one blank. ftfy (requirements.txt) is required exactly as in
+    the reference: without it mojibake would silently tokenise differently, so its absence is an error, not a fallback.
+    `fix_text` replaces ftfy.fix_text (tests; callers that repair their text upstream)."""
     import html
     import re
-    try:
-        import ftfy
-    except ImportError as e:  # pragma: no cover - depends on the environment
-        raise RuntimeError("prompt cleaning needs the `ftfy` package (the reference's tokenizer wrapper calls ftfy.fix_text); "
-                           "install it or pass pre-tokenised ids to encode_ids()") from e
-    text = html.unescape(html.unescape(ftfy.fix_text(text))).strip()
+    if fix_text is None:
+        try:
+            import ftfy
+        except ImportError as e:  # pragma: no cover - depends on the environment
+            raise RuntimeError("prompt cleaning needs the `ftfy` package (requirements.txt; the reference's tokenizer wrapper calls "
+                               "ftfy.fix_text); install it or pass pre-tokenised ids to encode_ids()") from e
+        fix_text = ftfy.fix_text
+    text = html.unescape(html.unescape(fix_text(text))).strip()
     return re.sub(r"\s+", " ", text).strip()
 
 

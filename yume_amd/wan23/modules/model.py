@@ -77,6 +77,13 @@ class WanAttentionBlock(nn.Module):
         object.__setattr__(self, "_owner", weakref.ref(model))
         object.__setattr__(self, "_index", index)
 
+    def __getstate__(self):
+        # a weakref cannot be pickled (torch.save(model), spawn workers); the owning WanModel re-binds its blocks in
+        # __setstate__, a block unpickled on its own has no owner (forward says so)
+        st = dict(self.__dict__)
+        st.pop("_owner", None)
+        return st
+
     @staticmethod
     def _rope_rows(freqs, grid, n_tokens, flag):
         """(cos, sin) rows [n, 64, 2] fp32 for the tokens that get RoPE. flag=True (FramePack): `freqs` is the per-token complex
@@ -277,7 +284,7 @@ class WanModel(nn.Module):
         return st
 
     def __setstate__(self, st):
-        self.__dict__.update(st)
+        super().__setstate__(st)          # nn.Module.__setstate__: state + the hook dictionaries older pickles lack
         self._bind_blocks()
 
     def enable_sequence_parallel(self, group=None):
