@@ -118,3 +118,20 @@ def test_oracle_block_residual_cache_matches_live_reference():
     out1, cache, out2 = _oracle_cache_run(cfg, sd, a, b, L, lfz, cache_list)
     assert (out1 - r1).abs().max() <= 2e-5 and (out2 - r2).abs().max() <= 2e-5
     assert [tuple(c.shape) for c in cache] == [tuple(c.shape) for c in rc]
+
+
+def test_oracle_block_matches_the_reference_block_at_full_width():
+    """tests/golden/block_bf16_deviation.pt (oracle/make_golden_bf16dev.py): the REAL reference WanAttentionBlock at full 5B width
+    (dim 3072, 24 heads, ffn 14336), L = 2048, 77 text tokens, fp32 on CPU. The oracle's block restatement — on the head-by-head
+    attention evaluation the full-size tests use (oracle/fullsize.py) — reproduces its rows to fp32 round-off."""
+    from oracle import fullsize
+    fx = load_golden("block_bf16_deviation")
+    case = fullsize.make_block_case(synth.CFG_5B, "wan23", fx["L"], seed=fx["seed"], n_text=fx["n_text"])
+    assert abs(float(case["x"].double().sum()) - fx["x_checksum"]) <= 1e-9 * abs(fx["x_checksum"]), "synthetic inputs drifted"
+    want, _ = fullsize.run_block_oracle(case)
+    err = (want[fx["rows"]] - fx["gold_rows"]).abs().max().item()
+    assert err <= 5e-5, err
+    # and the fixture's own statement of the reference's bf16 deviation is self-consistent on the stored rows
+    x = case["x"][fx["rows"]].double()
+    d = (fx["bf16_rows"].double() - fx["gold_rows"].double()).norm() / (fx["gold_rows"].double() - x).norm()
+    assert 0.5 * fx["reference_bf16_deviation"]["update_rel_l2"] <= d.item() <= 2.0 * fx["reference_bf16_deviation"]["update_rel_l2"]
