@@ -29,7 +29,8 @@ static float gelu_tanh(float x) { const float u = 0.7978845608028654f * (x + 0.0
 
 struct Case { int64_t M, N, K; int epi; int R; };   // R: gate rows (RESID), 0 = no gate
 
-static int run_case(const Case& c, int variant, bool full_check, bool timing, const char* tag) {
+static int run_case(const Case& c, const std::vector<int>& variants, int reps, bool full_check, bool timing) {
+    int total_bad = 0;
     const int64_t M = c.M, N = c.N, K = c.K;
     std::vector<uint16_t> a(M * K), w(N * K);
     const float ws = 1.0f / sqrtf((float)K);
@@ -51,8 +52,12 @@ static int run_case(const Case& c, int variant, bool full_check, bool timing, co
     HC(hipMemcpy(dbias, bias.data(), N * 4, hipMemcpyHostToDevice)); HC(hipMemcpy(dgate, gate.data(), gate.size() * 4, hipMemcpyHostToDevice));
     HC(hipMemcpy(dr, ridx.data(), M * 4, hipMemcpyHostToDevice));
     if (c.epi == YUME_EPI_BF16_SPLITT) { HC(hipMalloc(&dt, (N - nsplit) * ldt * 2)); HC(hipMemset(dt, 0, (N - nsplit) * ldt * 2)); }
+    for (int rep = 0; rep < reps; ++rep)
+    for (int variant : variants) {
+    const char* tag = variant == 3 ? (full_check ? "small/w4 " : "big/w4  ") : variant == 2 ? (full_check ? "small/256" : "big/256 ") : (full_check ? "small/auto" : "big/auto");
     if (c.epi == YUME_EPI_RESID) HC(hipMemcpy(dout, x0.data(), M * N * 4, hipMemcpyHostToDevice));
     else HC(hipMemset(dout, 0xff, M * N * osz));
+    if (dt) HC(hipMemset(dt, 0, (N - nsplit) * ldt * 2));
     auto call = [&]() {
         return p_gemm(da, K, dw, K, dbias, M, N, K, c.epi, dout, N, c.R > 0 ? dgate : nullptr, N, c.R > 1 ? dr : nullptr, dt, ldt, nsplit, variant, nullptr);
     };
@@ -86,8 +91,11 @@ static int run_case(const Case& c, int variant, bool full_check, bool timing, co
         if (!(err <= tol)) ++bad;
         maxerr = err > maxerr ? err : maxerr; maxref = fabs(want) > maxref ? fabs(want) : maxref;
     };
-    if (full_check) { for (int64_t m = 0; m < M; ++m) for (int64_t n = 0; n < N; ++n) check(m, n); }
-    else {
+    if (full_check) {
+        for (int64_t m = 0; m < M; ++m) for (int64_t n = 0; n < N; ++n) check(m, n);
+        // nothing may be written outside the matrix: the K-major image's pad columns [M, ldt) stay as memset
+        if (dt) for (int64_t n = 0; n < N - nsplit; ++n) for (int64_t m = M; m < ldt; ++m) if (outT[n * ldt + m] != 0) ++bad;
+    } else if (rep == 0) {
         for (int i = 0; i < 4096; ++i) {
             rs = rs * 6364136223846793005ull + 1442695040888963407ull;
             int64_t m = (rs >> 20) % M, n = (rs >> 40) % N;
@@ -110,17 +118,28 @@ static int run_case(const Case& c, int variant, bool full_check, bool timing, co
            variant, maxerr, maxref, bad, bad ? "FAIL" : "ok");
     if (timing) printf("   %.4f ms  %.0f TFLOP/s", ms, 2.0 * M * N * K / (ms * 1e-3) / 1e12);
     printf("\n");
+    fflush(stdout);
+    total_bad += bad;
+    }
     hipFree(da); hipFree(dw); hipFree(dout); hipFree(dbias); hipFree(dgate); hipFree(dr); if (dt) hipFree(dt);
-    return bad ? 1 : 0;
+    return total_bad ? 1 : 0;
 }
 
 int main(int argc, char** argv) {
     const char* lib = "yume_amd/lib/libyume_hip.so";
-    bool timing_only = false, quick = false;
+    bool timing_only = false, quick = false, expm = false;
+    std::vector<int> variants = {2, 3};        // 2 = 8-wave 256x256 kernel, 3 = one-wave-per-SIMD 256x256 kernel (gemm_w4.hpp), 0 = automatic
+    int reps = 2;
     for (int i = 1; i < argc; ++i) {
         if (!strcmp(argv[i], "--lib")) lib = argv[++i];
         else if (!strcmp(argv[i], "--timing")) timing_only = true;
-        else if (!strcmp(argv[i], "--quick")) { timing_only = true; quick = true; }     // the 5B shapes + 8192^3 on the 256^2 kernel only
+        else if (!strcmp(argv[i], "--quick")) { timing_only = true; quick = true; }     // the 5B shapes + 8192^3, the listed variants interleaved
+        else if (!strcmp(argv[i], "--exp")) { timing_only = true; expm = true; }         // experiment builds (bf16 epilogue only): the block's shapes with a plain epilogue
+        else if (!strcmp(argv[i], "--reps")) reps = atoi(argv[++i]);
+        else if (!strcmp(argv[i], "--variants")) {
+            variants.clear();
+            for (char* t = strtok(argv[++i], ","); t; t = strtok(nullptr, ",")) variants.push_back(atoi(t));
+        }
     }
     void* hnd = dlopen(lib, RTLD_NOW);
     if (!hnd) { printf("dlopen %s: %s\n", lib, dlerror()); return 2; }
@@ -132,17 +151,28 @@ int main(int argc, char** argv) {
         const Case small[] = {{256, 256, 64, YUME_EPI_F32, 0}, {256, 256, 128, YUME_EPI_F32, 0}, {512, 512, 192, YUME_EPI_BF16, 0}, {300, 512, 256, YUME_EPI_F32, 0},
                               {257, 768, 320, YUME_EPI_BF16_GELU, 0}, {1000, 512, 64, YUME_EPI_RESID, 0}, {777, 1024, 448, YUME_EPI_RESID, 3},
                               {520, 768, 256, YUME_EPI_BF16_SPLITT, 0}, {1024, 1536, 512, YUME_EPI_BF16_SPLITT, 0}, {256, 512, 1024, YUME_EPI_RESID, 1},
-                              {2048, 256, 3072, YUME_EPI_F32, 0}, {511, 2048, 576, YUME_EPI_BF16, 0}};
-        for (auto& c : small) fails += run_case(c, 2, true, false, "small");
+                              {2048, 256, 3072, YUME_EPI_F32, 0}, {511, 2048, 576, YUME_EPI_BF16, 0},
+                              // K tiles 2 .. 7 (every prologue / tail shape of the two-tiles-ahead pipeline), ragged M and N edges, every epilogue
+                              {512, 512, 128, YUME_EPI_BF16, 0}, {512, 256, 256, YUME_EPI_RESID, 2}, {260, 516, 320, YUME_EPI_BF16, 0},
+                              {1000, 768, 384, YUME_EPI_BF16_GELU, 0}, {999, 1000, 448, YUME_EPI_F32, 0}, {770, 2304, 192, YUME_EPI_BF16_SPLITT, 0},
+                              {1290, 1536, 640, YUME_EPI_BF16_SPLITT, 0}, {513, 260, 128, YUME_EPI_RESID, 0}, {768, 1024, 1024, YUME_EPI_RESID, 5}};
+        for (auto& c : small) fails += run_case(c, variants, 1, true, false);
     }
     const Case big[] = {{9460, 9216, 3072, YUME_EPI_BF16_SPLITT, 0}, {9460, 3072, 3072, YUME_EPI_RESID, 2}, {9460, 3072, 3072, YUME_EPI_RESID, 0},
                         {9460, 3072, 3072, YUME_EPI_BF16, 0}, {9460, 14336, 3072, YUME_EPI_BF16_GELU, 0}, {9460, 3072, 14336, YUME_EPI_RESID, 2},
                         {8192, 8192, 8192, YUME_EPI_BF16, 0}, {27810, 5120, 5120, YUME_EPI_RESID, 1}, {27810, 13824, 5120, YUME_EPI_BF16_GELU, 0}};
+    if (expm) {
+        const Case ex[] = {{9460, 3072, 3072, YUME_EPI_BF16, 0}, {9460, 14336, 3072, YUME_EPI_BF16, 0}, {9460, 3072, 14336, YUME_EPI_BF16, 0}, {8192, 8192, 8192, YUME_EPI_BF16, 0}};
+        for (auto& c : ex) fails += run_case(c, variants, reps, false, true);
+        printf("gemm_check: %d failure(s)\n", fails);
+        return fails ? 1 : 0;
+    }
     int nb = 0;
     for (auto& c : big) {
         if (quick && nb++ >= 7) break;
-        fails += run_case(c, 2, false, true, "big/256");
-        if (!quick) fails += run_case(c, 0, false, true, "big/auto");
+        std::vector<int> vs = variants;
+        if (!quick) vs.push_back(0);
+        fails += run_case(c, vs, quick ? reps : 1, false, true);
     }
     printf("gemm_check: %d failure(s)\n", fails);
     return fails ? 1 : 0;

@@ -13,7 +13,7 @@ for f in glob.glob(os.path.join(root, "*", "*_kernel_trace.csv")):
         dur[r["Kernel_Name"][:110]].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
 rows = []
 for k in acc:
-    if "gemm" not in k and "attn" not in k and "adaln" not in k and "conv" not in k: continue
+    if not any(t in k for t in ("gemm", "attn", "adaln", "conv", "Cijk", "norm")): continue
     d = {"kernel": k, "avg_us(profiled)": sum(dur[k]) / max(1, len(dur[k]))}
     for c, v in acc[k].items():
         d[c] = sum(v) / len(v)

@@ -1,6 +1,7 @@
 // gemm_bf16.hip — C-ABI of the dense bf16 MFMA GEMM (pipeline and epilogues: gemm_core.hpp).
 // Roofline: MFMA (bf16 dense 2.5 PFLOP/s); algorithmic work 2*M*N*K flop per launch.
 #include "gemm_core.hpp"
+#include "gemm_w4.hpp"
 
 using namespace gemm_core;
 
@@ -21,6 +22,11 @@ SideStream* side_stream() {
         made[dev] = true;
     }
     return &per_dev[dev];
+}
+// variant 0 (automatic) takes the one-wave-per-SIMD kernel (gemm_w4.hpp) wherever it took the 8-wave 256x256 kernel; YUME_GEMM_W4=0 keeps the latter
+bool w4_auto() {
+    static const bool on = [] { const char* v = getenv("YUME_GEMM_W4"); return !v || atoi(v) != 0; }();
+    return on;
 }
 }  // namespace
 
@@ -70,13 +76,13 @@ extern "C" int yume_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t
                 int rc = remainder((void*)ss->s);
                 if (rc != YUME_OK) return rc;
                 if (hipEventRecord(ss->join, ss->s) != hipSuccess) { yume_set_error("gemm_bf16: side stream join failed"); return YUME_ELAUNCH; }
-                rc = yume_gemm_bf16(A, lda, W, ldw, bias, M_main, N, K, epi, out, ldo, gate, gate_stride, row_idx, outT, ldt, n_split, 2, stream);
+                rc = yume_gemm_bf16(A, lda, W, ldw, bias, M_main, N, K, epi, out, ldo, gate, gate_stride, row_idx, outT, ldt, n_split, w4_auto() ? 3 : 2, stream);
                 if (rc != YUME_OK) return rc;
                 if (hipStreamWaitEvent(st, ss->join, 0) != hipSuccess) { yume_set_error("gemm_bf16: side stream join failed"); return YUME_ELAUNCH; }
                 return YUME_OK;
             }
             int rc = yume_gemm_bf16(A, lda, W, ldw, bias, M_main, N, K, epi, out, ldo, gate, gate_stride, row_idx, outT, ldt, n_split,
-                                    2, stream);
+                                    w4_auto() ? 3 : 2, stream);
             if (rc != YUME_OK) return rc;
             return remainder(stream);
         }
@@ -89,8 +95,12 @@ extern "C" int yume_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t
     e.gate = gate; e.gate_stride = gate_stride; e.row_idx = row_idx;
     e.outT = (unsigned short*)outT; e.ldt = ldt; e.n_split = (int)n_split;
     hipStream_t st = (hipStream_t)stream;
-    const bool big = use_256(p, variant, epi != YUME_EPI_BF16_SPLITT || (n_split % 256) == 0);
-#define YUME_GO(E) (big ? launch256<E>(p, al, e, st, "gemm_bf16") : launch<E>(p, al, e, st, "gemm_bf16"))
+    const bool split_ok = epi != YUME_EPI_BF16_SPLITT || (n_split % 256) == 0;
+    const bool big = use_256(p, variant == 3 ? 2 : variant, split_ok);
+    // variant 3: the one-wave-per-SIMD 256x256 kernel where it applies (else as variant 2); variant 0 takes it wherever it took the 8-wave kernel
+    const bool w4 = (variant == 3 || (variant == 0 && big && w4_auto())) && split_ok && gemm_w4::w4_applies(p, lda, epi) &&
+                    (epi != YUME_EPI_BF16_SPLITT || (ldt % 8) == 0);
+#define YUME_GO(E) (w4 ? gemm_w4::launch_w4(E, p, al, e, st, "gemm_bf16") : big ? launch256<E>(p, al, e, st, "gemm_bf16") : launch<E>(p, al, e, st, "gemm_bf16"))
     switch (epi) {
         case YUME_EPI_BF16: return YUME_GO(YUME_EPI_BF16);
         case YUME_EPI_BF16_GELU: return YUME_GO(YUME_EPI_BF16_GELU);

@@ -801,8 +801,8 @@ inline int read_mode_env() {
 static const int g_mode256 = read_mode_env();   // -1: use the caller's default
 inline int read_group_env() {
     const char* v = getenv("YUME_GEMM_GROUPM");
-    const int g = v ? atoi(v) : 4;
-    return g > 0 ? g : 4;
+    const int g = v ? atoi(v) : 8;
+    return g > 0 ? g : 8;
 }
 static const int g_group_m = read_group_env();
 

@@ -1,0 +1,445 @@
+// gemm_w4.hpp — the dense bf16 GEMM with ONE wave per SIMD (r3):   acc[m,n] = sum_k A[m,k] * W[n,k],   256 x 256 x 64 tiles.
+//
+// Why another schedule. The 8-wave kernel of gemm_core.hpp (two waves per SIMD, each 128 x 64 of the tile) issues, per 64 MFMAs of a
+// wave, 24 fragment reads, 8 LDS-DMA pieces with per-lane 64-bit addresses and 8 workgroup barriers: its matrix pipe is 56-70 % busy
+// (profiles/r2_rejected_experiments.md). The vendor library's best kernel for these shapes (rocprofv3: `..._MT256x256x64_MI16x16x1`;
+// its code object says 256 threads, 133,120 B of LDS, 249 VGPRs + accumulators) reaches 87 %: four waves, one per SIMD, each owning a
+// 128 x 128 quarter = 64 accumulators of 16x16 = all 256 AGPRs. Per K tile a wave then issues 128 MFMAs against 32 fragment reads
+// (0.25 per MFMA instead of 0.375), 16 DMA pieces and a few barriers, everything placed one filler per MFMA gap.
+// This file is that structure written for this library's operand layout:
+//   * 4 waves (2 x 2), wave (wr, wc) owns rows wr*128 + [0,128), columns wc*128 + [0,128) of the tile: accumulator tile (i, j)
+//     (16 x 16) lives in a[(i*8+j)*4 .. +3]. The AGPRs are OWNED by this file: named literally in the MFMA statements and listed as
+//     clobbers (the convention of attn_fwd7.hip; tests/test_gemm_w4_isa.py audits the compiled loop for it);
+//   * LDS: two K-tile buffers of A | B, each operand a row-major [256][64] bf16 image (128-byte rows) with the bank swizzle of
+//     gemm_core.hpp applied on the DMA source (16-byte chunk c of row r holds logical chunk c ^ (r & 7)): 128 KiB;
+//   * a K tile = two k-steps of 32; fragment sets F0 / F1 (8 A + 8 B fragments each, 128 VGPRs together);
+//         segment 1: 64 MFMAs on F0(t); the 16 reads of F1(t) ride in its first gaps; `lgkmcnt(0)` + barrier (every wave is done
+//                    with buffer t); the 16 DMA pieces of tile t+2 (into the buffer tile t just left) ride in MFMA statements
+//         segment 2: 64 MFMAs on F1(t); counted `vmcnt` (tile t+1 landed: its pieces were issued a whole K tile ago) + barrier;
+//                    the 16 reads of F0(t+1)
+//     = 2 barriers and 2 waits per 128 MFMAs; no VALU and ~10 SALU inside the loop (source pointers advance by 128 bytes per tile;
+//     M0 = SGPR + literal inside the DMA statement; per-lane source offsets are loop-invariant VGPRs, row-clamped at the M / N edge);
+//   * epilogues as in gemm_core.hpp: bf16 tiles leave through an LDS image as whole 512-byte rows (the K-major V^T tiles too, as whole
+//     rows of 256 tokens), fp32 / residual tiles straight from the accumulators with their loads batched.
+// Roofline: MFMA bf16 dense; 2*M*N*K flop per launch.
+#pragma once
+#include "gemm_core.hpp"
+
+namespace gemm_w4 {
+using namespace gemm_core;
+
+constexpr int NTHR_W4 = 256;
+constexpr int OPER_BYTES = 256 * 128;        // one operand of one K tile
+constexpr int BUF_BYTES = 2 * OPER_BYTES;    // A | B
+constexpr int LDS_W4 = 2 * BUF_BYTES;        // 128 KiB
+
+#define W4_AG8(n) "a" #n "0", "a" #n "1", "a" #n "2", "a" #n "3", "a" #n "4", "a" #n "5", "a" #n "6", "a" #n "7", "a" #n "8", "a" #n "9"
+#define W4_AGPRS "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", W4_AG8(1), W4_AG8(2), W4_AG8(3), W4_AG8(4), W4_AG8(5), W4_AG8(6), \
+    W4_AG8(7), W4_AG8(8), W4_AG8(9), W4_AG8(10), W4_AG8(11), W4_AG8(12), W4_AG8(13), W4_AG8(14), W4_AG8(15), W4_AG8(16), W4_AG8(17), W4_AG8(18), \
+    W4_AG8(19), W4_AG8(20), W4_AG8(21), W4_AG8(22), W4_AG8(23), W4_AG8(24), "a250", "a251", "a252", "a253", "a254", "a255"
+
+// acc tiles T0, T1 (T = i*8 + j) += X * Y    (X = first MFMA operand: its 16 rows become the 4-consecutive index of the result lane).
+// Two MFMAs per statement: hipcc pads every boundary between two asm statements with an s_nop, which would take an issue slot per MFMA gap.
+#define W4_MFMA2(T0, X0, Y0, T1, X1, Y1)                                                                                                         \
+    asm volatile("v_mfma_f32_16x16x32_bf16 a[%c4:%c5], %0, %1, a[%c4:%c5]\n\tv_mfma_f32_16x16x32_bf16 a[%c6:%c7], %2, %3, a[%c6:%c7]"             \
+                 ::"v"(X0), "v"(Y0), "v"(X1), "v"(Y1), "n"((T0) * 4), "n"((T0) * 4 + 3), "n"((T1) * 4), "n"((T1) * 4 + 3) : "memory", W4_AGPRS)
+// ... carrying one LDS-DMA piece: 64 lanes x 16 bytes from sbase + voff[lane] to LDS bytes [lbase + loff, + 1024). M0 is written in
+// front of the first MFMA, which is the wait state the LDS-DMA needs behind an M0 write.
+#define W4_MFMA2_DMA(T0, X0, Y0, T1, X1, Y1, voff, sbase, lbase, loff)                                                                            \
+    asm volatile("s_add_u32 m0, %10, %11\n\tv_mfma_f32_16x16x32_bf16 a[%c4:%c5], %0, %1, a[%c4:%c5]\n\tglobal_load_lds_dwordx4 %8, %9\n\t"         \
+                 "v_mfma_f32_16x16x32_bf16 a[%c6:%c7], %2, %3, a[%c6:%c7]"                                                                       \
+                 ::"v"(X0), "v"(Y0), "v"(X1), "v"(Y1), "n"((T0) * 4), "n"((T0) * 4 + 3), "n"((T1) * 4), "n"((T1) * 4 + 3), "v"(voff), "s"(sbase),   \
+                 "s"(lbase), "n"(loff) : "memory", "scc", W4_AGPRS)
+// a stand-alone piece (prologue)
+#define W4_DMA(voff, sbase, lbase, loff) \
+    asm volatile("s_add_u32 m0, %2, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lbase), "n"(loff) : "memory", "scc")
+
+template <int R>
+__device__ __forceinline__ f32x4 acc_tile() {      // accumulator tile R -> VGPRs
+    f32x4 v;
+    asm volatile("v_accvgpr_read_b32 %0, a[%c4]\n\tv_accvgpr_read_b32 %1, a[%c5]\n\tv_accvgpr_read_b32 %2, a[%c6]\n\tv_accvgpr_read_b32 %3, a[%c7]"
+                 : "=v"(v[0]), "=v"(v[1]), "=v"(v[2]), "=v"(v[3]) : "n"(R * 4), "n"(R * 4 + 1), "n"(R * 4 + 2), "n"(R * 4 + 3) : W4_AGPRS);
+    return v;
+}
+template <int R0, int N>
+__device__ __forceinline__ void acc_zero() {
+    if constexpr (N > 0) {
+        asm volatile("v_accvgpr_write_b32 a[%c0], 0\n\tv_accvgpr_write_b32 a[%c1], 0\n\tv_accvgpr_write_b32 a[%c2], 0\n\tv_accvgpr_write_b32 a[%c3], 0"
+                     ::"n"(R0), "n"(R0 + 1), "n"(R0 + 2), "n"(R0 + 3) : W4_AGPRS);
+        acc_zero<R0 + 4, N - 4>();
+    }
+}
+template <int I0, int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (N > 0) {
+        f(std::integral_constant<int, I0>{});
+        static_for<I0 + 1, N - 1>(f);
+    }
+}
+
+struct Ctx {
+    char* smem;
+    bf16x8_t fa[2][8], fb[2][8];    // fragment sets [k-step][i or j]
+    // per-lane LDS byte offsets of fragment 0 (fragment i: + i * 2048): k-step 1 in the buffer of the CURRENT tile, k-step 0 in the buffer of
+    // the NEXT tile; all four flip (^ BUF_BYTES) after every tile
+    unsigned ra1, rb1, ra0n, rb0n;
+    unsigned va[8], vb[8];          // per-lane source byte offsets of this wave's 8 DMA pieces per operand (row-clamped, chunk-swizzled)
+    const char* pa;                 // A tile base + K offset of the tile to stage next (wave-uniform)
+    const char* pb;
+    unsigned lcur;                  // LDS byte address of this wave's 1 KiB piece slot in the CURRENT tile's buffer (= the one tile t+2 is staged into)
+};
+
+__device__ __forceinline__ bf16x8_t w4_frag(const Ctx& c, unsigned off) { return *reinterpret_cast<const bf16x8_t*>(c.smem + off); }
+
+// piece q (0..15) of a K tile inside its buffer: q < 8 -> A piece q, else W piece q - 8. Piece j of a wave = rows 32 j + 8 w + [0,8).
+#define W4_PIECE_LOFF(q) (((q) >> 3) * OPER_BYTES + ((q) & 7) * 4096)
+
+// One K tile = 128 MFMAs g = 0..127: k-step g >> 6, accumulator tile n = g & 63 = (i, j) = (n >> 3, n & 7). The body exists twice per
+// operand order: staging tile t+2 (tiles 0 .. nk-3) and not staging (the last two); the buffers alternate through run-time offsets and
+// the last tile reads fragments nobody uses. (Five prologue / tail variants inlined behind one another made hipcc's register allocation
+// spill — through a[0:3], this file's accumulator; re-staging the last K tile instead of a second body cost +15 % fabric reads: the
+// copies always miss the L2.)
+// (plain recursive templates, not generic lambdas: clang does not capture a local for an asm operand inside a generic lambda)
+#define W4_X(g) (SWAP ? c.fb[(g) >> 6][(g) & 7] : c.fa[(g) >> 6][((g) & 63) >> 3])
+#define W4_Y(g) (SWAP ? c.fa[(g) >> 6][((g) & 63) >> 3] : c.fb[(g) >> 6][(g) & 7])
+#define W4_PAIR(g) W4_MFMA2((g) & 63, W4_X(g), W4_Y(g), ((g) + 1) & 63, W4_X((g) + 1), W4_Y((g) + 1))
+#define W4_PAIR_DMA(g, voff, sbase, loff) \
+    W4_MFMA2_DMA((g) & 63, W4_X(g), W4_Y(g), ((g) + 1) & 63, W4_X((g) + 1), W4_Y((g) + 1), voff, sbase, c.lcur, loff)
+
+// ---- the gap plan of a K tile ------------------------------------------------------------------------------------------------------
+// The MFMAs go two per asm statement ("slot" k = MFMAs 2k, 2k+1): what rides inside a slot (a DMA piece, between its two MFMAs) or behind
+// it (a fragment read, a barrier) is the plan below.
+// (r3, measured and removed again: running the four waves in four PHASES — statement grouping shifted by one MFMA, fillers by one slot —
+// so that their DMA pieces and fragment reads reach the CU's one vector-memory path / LDS 16 clocks apart instead of in the same clock:
+// no change, +-1 %. Neither did removing every wait and barrier of the loop (stale data, timing only). The kernel runs at the package
+// power limit — 1.53-1.65 GHz in the PMC passes — where parked cycles cost nothing and wall time follows the ENERGY of a tile:
+// profiles/r3_gemm_w4.md.)
+#ifndef W4_PLAN
+#define W4_PLAN 1
+#endif
+#ifndef W4_ABLATE
+#define W4_ABLATE 0      // experiments only: 1 = no DMA inside the loop (stale operands), 2 = no fragment reads, 4 = no barriers, 8 = no vmcnt wait, 16 = no lgkmcnt(0) at barrier A
+#endif
+#ifndef W4_BAR_B
+#define W4_BAR_B 35
+#endif
+#ifndef W4_BAR_A
+#define W4_BAR_A 17
+#endif
+#ifndef W4_DMA0
+#define W4_DMA0 (W4_BAR_A + 2)
+#endif
+constexpr int P_BAR_A = W4_BAR_A;    // behind this slot: lgkmcnt(0) + barrier (all of buffer t has been read)
+constexpr int P_BAR_B = W4_BAR_B;    // behind this slot: counted vmcnt + barrier (tile t+1 landed and visible)
+// DMA piece q of tile t+2 rides in plan position dma_pos(q). PLAN 0: one piece in every slot from 19 on (a burst); PLAN 1: the 16 pieces
+// spread over positions 19..63 (one per ~3 slots: 1 KiB per ~24 clocks per CU, under the vector-memory path's 64 B/clk; +5 % at 8192^3, +12 %
+// at the ffn.2 shape over the burst).
+constexpr int dma_pos(int q) { return W4_PLAN == 0 ? W4_DMA0 + q : W4_DMA0 + (q * (63 - W4_DMA0)) / 15; }
+constexpr int piece_at(int pos) {
+    for (int q = 0; q < 16; ++q)
+        if (dma_pos(q) == pos) return q;
+    return -1;
+}
+constexpr int pieces_before_bar_b() {      // pieces of tile t+2 already issued when the wait for tile t+1 comes
+    int k = 0;
+    for (int q = 0; q < 16; ++q) k += dma_pos(q) <= P_BAR_B ? 1 : 0;
+    return k;
+}
+// fragment reads: F1(t) read r at plan position r (r = 0..15); F0(t+1) read r at position P_F0_FIRST + r
+constexpr int P_F0_FIRST = P_BAR_B + 2;
+static_assert(P_F0_FIRST + 16 <= 64 && dma_pos(15) <= 63 && 15 < P_BAR_A && dma_pos(0) > P_BAR_A, "the plan must fit the 64 slots");
+
+template <int g, bool DMA, bool SWAP>
+__device__ __forceinline__ void w4_gaps(Ctx& c) {
+    if constexpr (g < 128) {
+        {
+            constexpr int k = g >> 1, pos = k;                 // slot = plan position
+            constexpr int q = (DMA && !(W4_ABLATE & 1)) ? piece_at(pos) : -1;
+            if constexpr (q >= 0 && q < 8) W4_PAIR_DMA(g, c.va[q & 7], c.pa, W4_PIECE_LOFF(q & 15));
+            else if constexpr (q >= 8) W4_PAIR_DMA(g, c.vb[q & 7], c.pb, W4_PIECE_LOFF(q & 15));
+            else W4_PAIR(g);
+            if constexpr (pos >= 0 && pos < 16 && !(W4_ABLATE & 2)) {     // F1(t): the W fragments first (segment 2's first 8 MFMAs need all eight)
+                if constexpr (pos < 8) c.fb[1][pos & 7] = w4_frag(c, c.rb1 + (pos & 7) * 2048);
+                else c.fa[1][pos & 7] = w4_frag(c, c.ra1 + (pos & 7) * 2048);
+            }
+            if constexpr (k == P_BAR_A) {
+                if constexpr ((W4_ABLATE & 20) == 20) asm volatile("" ::: "memory");
+                else if constexpr (W4_ABLATE & 16) asm volatile("s_barrier" ::: "memory");
+                else if constexpr (W4_ABLATE & 4) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            }
+            if constexpr (k == P_BAR_B) {
+                // tile t+1 complete (this wave's pieces; the pieces of tile t+2 issued so far may stay in flight), then visible to all waves
+                constexpr int keep = (DMA && !(W4_ABLATE & 1)) ? pieces_before_bar_b() : 0;
+                if constexpr ((W4_ABLATE & 12) == 12) asm volatile("" ::: "memory");
+                else if constexpr (W4_ABLATE & 8) asm volatile("s_barrier" ::: "memory");
+                else if constexpr (W4_ABLATE & 4) asm volatile("s_waitcnt vmcnt(%c0)" ::"n"(keep) : "memory");
+                else asm volatile("s_waitcnt vmcnt(%c0)\n\ts_barrier" ::"n"(keep) : "memory");
+            }
+            if constexpr (pos >= P_F0_FIRST && pos < P_F0_FIRST + 16 && !(W4_ABLATE & 2)) {
+                constexpr int r = pos - P_F0_FIRST;
+                if constexpr (r < 8) c.fb[0][r & 7] = w4_frag(c, c.rb0n + (r & 7) * 2048);
+                else c.fa[0][r & 7] = w4_frag(c, c.ra0n + (r & 7) * 2048);
+            }
+            w4_gaps<g + 2, DMA, SWAP>(c);
+        }
+    }
+}
+// the 16 pieces of one K tile, stand-alone (prologue)
+template <int q>
+__device__ __forceinline__ void w4_stage_all(Ctx& c) {
+    if constexpr (q < 16) {
+        if constexpr (q < 8) W4_DMA(c.va[q & 7], c.pa, c.lcur, W4_PIECE_LOFF(q));
+        else W4_DMA(c.vb[q & 7], c.pb, c.lcur, W4_PIECE_LOFF(q));
+        w4_stage_all<q + 1>(c);
+    }
+}
+
+// ---- epilogue ---------------------------------------------------------------------------------------------------------------------
+// SWAP tiles: a lane holds C[m][n .. n+3], m = m0 + wr*128 + 16 i + (lane & 15), n = n0 + wc*128 + 16 j + 4 (lane >> 4).
+// !SWAP tiles (K-major V^T): C[m .. m+3][n], m = m0 + wr*128 + 16 i + 4 (lane >> 4), n = n0 + wc*128 + 16 j + (lane & 15).
+template <int EPI>
+__device__ __forceinline__ f32x4 w4_act(f32x4 v) {
+    if (EPI == YUME_EPI_BF16_GELU) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = gelu_tanh(v[q]);
+    }
+    if (EPI == YUME_EPI_BF16_GELU_ERF) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = 0.5f * v[q] * (1.0f + erff(v[q] * 0.7071067811865476f));
+    }
+    return v;
+}
+
+// bf16 tile image in LDS: [256 rows][512 B], 16-byte chunk c of row r at chunk c ^ (r & 31); stored as whole rows (1 KiB per wave store).
+// rows = output rows of `dst` (tokens m for row-major outputs, features n for the K-major V^T), cols the contiguous index.
+__device__ __forceinline__ void w4_store_image(char* smem, unsigned short* dst, int64_t ld, int row0, int rows_valid, int col0, int cols_valid) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    unsigned short* out = dst + col0 + (lane & 31) * 8;
+    const bool col_ok = (lane & 31) * 8 + 8 <= cols_valid;
+    const int col_left = cols_valid - (lane & 31) * 8;          // elements of this lane's chunk inside the matrix (ragged last chunk)
+#pragma unroll 8
+    for (int it = 0; it < 32; ++it) {
+        const int r = wave * 64 + it * 2 + (lane >> 5);
+        const u32x4 d = *reinterpret_cast<const u32x4*>(smem + r * 512 + ((((lane & 31) ^ r) & 31) << 4));
+        if (r < rows_valid) {
+            unsigned short* o = out + (int64_t)(row0 + r) * ld;
+            if (col_ok) {
+                *reinterpret_cast<u32x4*>(o) = d;
+            } else if (col_left > 0) {
+                const unsigned short* s = reinterpret_cast<const unsigned short*>(&d);
+                for (int q = 0; q < col_left; ++q) o[q] = s[q];
+            }
+        }
+    }
+}
+
+template <int EPI, bool SWAP>
+__device__ __forceinline__ void w4_epilogue(const Problem& p, const Epilogue& e, int m0, int n0, char* smem) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    constexpr bool BF16_OUT = EPI == YUME_EPI_BF16 || EPI == YUME_EPI_BF16_GELU || EPI == YUME_EPI_BF16_GELU_ERF || EPI == YUME_EPI_BF16_SPLITT;
+    if constexpr (!SWAP) {
+        // K-major V^T tile: image rows = features n, columns = tokens m; whole rows of up to 256 tokens leave as 16-byte stores
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        static_for<0, 64>([&](auto tt) {
+            constexpr int T = decltype(tt)::value, i = T >> 3, j = T & 7;
+            f32x4 v = acc_tile<T>();
+            const int nl = wc * 128 + 16 * j + l15;                 // image row
+            const int ml = wr * 128 + 16 * i + 4 * l4;              // image column (4 consecutive)
+            const float bn = e.bias ? e.bias[min(n0 + nl, p.N - 1)] : 0.f;
+            u32x2 o;
+            o[0] = pack_bf16x2(v[0] + bn, v[1] + bn);
+            o[1] = pack_bf16x2(v[2] + bn, v[3] + bn);
+            *reinterpret_cast<u32x2*>(smem + nl * 512 + ((((ml >> 3) ^ nl) & 31) << 4) + ((ml >> 2) & 1) * 8) = o;
+        });
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        w4_store_image(smem, e.outT + (int64_t)(n0 - e.n_split) * e.ldt, e.ldt, 0, min(256, p.N - n0), m0, min(256, p.M - m0));
+        return;
+    } else {
+        if (BF16_OUT && !p.epi_direct && (e.ldo % 8) == 0) {         // (workgroup-uniform)
+            f32x4 b[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int n = n0 + wc * 128 + 16 * j + 4 * l4;
+                b[j] = (e.bias && n + 3 < p.N) ? *reinterpret_cast<const f32x4*>(e.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            static_for<0, 64>([&](auto tt) {
+                constexpr int T = decltype(tt)::value, i = T >> 3, j = T & 7;
+                const f32x4 v = w4_act<EPI>(acc_tile<T>() + b[j]);
+                const int r = wr * 128 + 16 * i + l15;
+                const int cc = wc * 128 + 16 * j + 4 * l4;
+                u32x2 o;
+                o[0] = pack_bf16x2(v[0], v[1]);
+                o[1] = pack_bf16x2(v[2], v[3]);
+                *reinterpret_cast<u32x2*>(smem + r * 512 + ((((cc >> 3) ^ r) & 31) << 4) + ((cc >> 2) & 1) * 8) = o;
+            });
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            w4_store_image(smem, reinterpret_cast<unsigned short*>(e.out), e.ldo, m0, min(256, p.M - m0), n0, min(256, p.N - n0));
+            return;
+        }
+        const bool whole = m0 + 256 <= p.M && n0 + 256 <= p.N;       // (workgroup-uniform)
+        if (EPI == YUME_EPI_RESID && whole) {
+            // fp32 residual stream, in place: x += (acc + bias) * gate. Per 16-row block i: the 8 x-loads (and gate loads) of the wave's 128
+            // columns are in flight together before the first use.
+            f32x4 b[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                b[j] = e.bias ? *reinterpret_cast<const f32x4*>(e.bias + n0 + wc * 128 + 16 * j + 4 * l4) : f32x4{0.f, 0.f, 0.f, 0.f};
+            static_for<0, 8>([&](auto ii) {
+                constexpr int i = decltype(ii)::value;
+                const int m = m0 + wr * 128 + 16 * i + l15;
+                float* xo = reinterpret_cast<float*>(e.out) + (int64_t)m * e.ldo + n0 + wc * 128 + 4 * l4;
+                f32x4 x[8], g[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) x[j] = *reinterpret_cast<const f32x4*>(xo + 16 * j);
+                if (e.gate) {
+                    const int64_t grow = e.row_idx ? (int64_t)e.row_idx[m] * e.gate_stride : 0;
+                    const float* gp = e.gate + grow + n0 + wc * 128 + 4 * l4;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) g[j] = *reinterpret_cast<const f32x4*>(gp + 16 * j);
+                }
+                static_for<0, 8>([&](auto jj) {
+                    constexpr int j = decltype(jj)::value;
+                    const f32x4 v = acc_tile<i * 8 + j>() + b[j];
+                    if (e.gate) x[j] += v * g[j];
+                    else x[j] += v;
+                    *reinterpret_cast<f32x4*>(xo + 16 * j) = x[j];
+                });
+            });
+            return;
+        }
+        static_for<0, 64>([&](auto tt) {
+            constexpr int T = decltype(tt)::value, i = T >> 3, j = T & 7;
+            const f32x4 v = acc_tile<T>();
+            const int m = m0 + wr * 128 + 16 * i + l15, n = n0 + wc * 128 + 16 * j + 4 * l4;
+            if (m < p.M && n < p.N) store_row4<EPI>(v, m, n, p, e);
+        });
+    }
+}
+
+// the K loop: tiles 0 .. nk-3 stage the tile two ahead, the last two stage nothing (a second instance of the body)
+template <bool DMA, bool SWAP>
+__device__ __forceinline__ void w4_loop(Ctx& c, int t0, int t1, unsigned lbase) {
+    for (int t = t0; t < t1; ++t) {
+        w4_gaps<0, DMA, SWAP>(c);
+        if constexpr (DMA) {
+            c.pa += 128;
+            c.pb += 128;
+        }
+        c.lcur = lbase + (((t + 1) & 1) ? BUF_BYTES : 0);
+        c.ra1 ^= BUF_BYTES;
+        c.rb1 ^= BUF_BYTES;
+        c.ra0n ^= BUF_BYTES;
+        c.rb0n ^= BUF_BYTES;
+    }
+}
+
+template <bool SWAP>
+__device__ __forceinline__ void w4_mainloop(const Problem& p, const PlainA& al, char* smem, int m0, int n0) {
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+    Ctx c;
+    c.smem = smem;
+    const unsigned lbase = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem + wave * 1024;
+    c.lcur = lbase;
+    c.pa = reinterpret_cast<const char*>(al.A + (int64_t)m0 * al.lda);
+    c.pb = reinterpret_cast<const char*>(p.W + (int64_t)n0 * p.ldw);
+    const unsigned lda_b = (unsigned)al.lda * 2u, ldw_b = (unsigned)p.ldw * 2u;
+    // DMA piece j of this wave: rows 32 j + 8 wave + (lane >> 3) of the tile, 16-byte chunk (lane & 7) ^ (row & 7) of the 128-byte K slice
+    {
+        const int rl = 8 * wave + (lane >> 3);
+        const unsigned ch = (unsigned)(((lane & 7) ^ (rl & 7)) << 4);
+        const int mleft = p.M - 1 - m0, nleft = p.N - 1 - n0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int r = 32 * j + rl;
+            c.va[j] = (unsigned)min(r, mleft) * lda_b + ch;
+            c.vb[j] = (unsigned)min(r, nleft) * ldw_b + ch;
+        }
+    }
+    // fragment reads: row (lane & 15) of fragment i (rows 16 i + ...) of this wave's half, logical chunk 4 ks + (lane >> 4), swizzled
+    const unsigned sw0 = (unsigned)(((lane >> 4) ^ (lane & 7)) << 4), sw1 = (unsigned)(((4 | (lane >> 4)) ^ (lane & 7)) << 4);
+    const unsigned rowa = wr * 16384 + (lane & 15) * 128, rowb = OPER_BYTES + wc * 16384 + (lane & 15) * 128;
+    const int nk = p.K / BK;
+    // ---- prologue: tiles 0 and 1 in flight, accumulators zeroed under their latency, F0(0) read ----
+    w4_stage_all<0>(c);
+    c.pa += 128;
+    c.pb += 128;
+    c.lcur = lbase + BUF_BYTES;
+    w4_stage_all<0>(c);
+    c.pa += 128;
+    c.pb += 128;
+    c.lcur = lbase;
+    acc_zero<0, 256>();
+    asm volatile("s_waitcnt vmcnt(16)\n\ts_barrier" ::: "memory");
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        c.fb[0][r] = w4_frag(c, rowb + sw0 + r * 2048);
+        c.fa[0][r] = w4_frag(c, rowa + sw0 + r * 2048);
+    }
+    c.ra1 = rowa + sw1;
+    c.rb1 = rowb + sw1;
+    c.ra0n = BUF_BYTES + rowa + sw0;
+    c.rb0n = BUF_BYTES + rowb + sw0;
+    // ---- main loop ----
+    w4_loop<true, SWAP>(c, 0, nk - 2, lbase);
+    w4_loop<false, SWAP>(c, nk - 2, nk, lbase);
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");     // every wave is done with its fragments: the epilogue reuses the LDS
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");      // last MFMA results -> v_accvgpr_read
+}
+
+// ONE kernel for every epilogue (the epilogue id is a kernel argument: the 128-MFMA loop body exists in 2 operand orders x {staging, not
+// staging} already, and instances of it that meet at a join made hipcc's register allocation spill through the accumulators)
+__global__ __launch_bounds__(NTHR_W4, 1) void gemm_w4_kernel(Problem p, PlainA al, Epilogue e, int epi) {
+    __shared__ __attribute__((aligned(16))) char smem[LDS_W4];
+    int start, count, m0, n0;
+    xcd_chunk(p.tiles_m * p.tiles_n, blockIdx.x & 7, start, count);
+    tile_origin(p, start + (blockIdx.x >> 3), m0, n0);
+    if (epi == YUME_EPI_BF16_SPLITT && n0 >= e.n_split) {
+        w4_mainloop<false>(p, al, smem, m0, n0);
+        w4_epilogue<YUME_EPI_BF16_SPLITT, false>(p, e, m0, n0, smem);
+        return;
+    }
+    w4_mainloop<true>(p, al, smem, m0, n0);
+    switch (epi) {
+#ifndef W4_EXPERIMENT
+        case YUME_EPI_BF16_GELU: w4_epilogue<YUME_EPI_BF16_GELU, true>(p, e, m0, n0, smem); break;
+        case YUME_EPI_BF16_GELU_ERF: w4_epilogue<YUME_EPI_BF16_GELU_ERF, true>(p, e, m0, n0, smem); break;
+        case YUME_EPI_F32: w4_epilogue<YUME_EPI_F32, true>(p, e, m0, n0, smem); break;
+        case YUME_EPI_RESID: w4_epilogue<YUME_EPI_RESID, true>(p, e, m0, n0, smem); break;
+        case YUME_EPI_BF16_SPLITT: w4_epilogue<YUME_EPI_BF16_SPLITT, true>(p, e, m0, n0, smem); break;
+#endif
+        default: w4_epilogue<YUME_EPI_BF16, true>(p, e, m0, n0, smem); break;
+    }
+}
+
+// shapes the kernel takes: at least two K tiles; 32-bit per-lane source offsets inside a tile's 256 rows
+inline bool w4_applies(const Problem& p, int64_t lda, int epi) {
+    if (p.K < 3 * BK) return false;
+#ifdef W4_EXPERIMENT
+    if (epi != YUME_EPI_BF16) return false;
+#endif
+    if (255ll * lda * 2 + 128 >= (1ll << 32) || 255ll * p.ldw * 2 + 128 >= (1ll << 32)) return false;
+    return epi == YUME_EPI_BF16 || epi == YUME_EPI_BF16_GELU || epi == YUME_EPI_BF16_GELU_ERF || epi == YUME_EPI_F32 || epi == YUME_EPI_RESID ||
+           epi == YUME_EPI_BF16_SPLITT;
+}
+
+inline int launch_w4(int epi, const Problem& p128, const PlainA& al, const Epilogue& e, hipStream_t st, const char* what) {
+    Problem p = p128;
+    p.tiles_m = (p.M + 255) / 256;
+    p.tiles_n = (p.N + 255) / 256;
+    p.group_m = g_group_m;
+    { static const int d = [] { const char* v = getenv("YUME_GEMM_EPI_DIRECT"); return v ? atoi(v) : 0; }(); p.epi_direct = d; }
+    hipLaunchKernelGGL(gemm_w4_kernel, dim3((unsigned)(p.tiles_m * p.tiles_n)), dim3(NTHR_W4), 0, st, p, al, e, epi);
+    YUME_CHECK_LAUNCH(what);
+    return YUME_OK;
+}
+
+}  // namespace gemm_w4
