@@ -82,6 +82,7 @@ struct ConvA {
             }
         }
     }
+    __device__ __forceinline__ int wk(int kt, bool /*behind*/) const { return kt * BK; }      // K walked in the weight's own order
 };
 
 
@@ -102,8 +103,10 @@ struct ConvAFast {
     const unsigned short* xbase[4];
     unsigned mask[4];
     int t0[4];
-    // uniform state
+    // uniform state: position (dt, dh, cin, dw) of the K walk and the element offset of that K tile inside a weight row (and of the tile before)
     int cin, dt, dh, dw, tap;
+    int wcur, wprev;
+    int dw_inner;     // 1 (default): walk K with dw innermost; 0 (env YUME_CONV_KORDER=0, A/B): the weight's own order
 
     __device__ __forceinline__ void init(int m0, int tid, int rpr = 32, int kshift = 0) {
         const int lc = (tid & 7) ^ (((tid >> 3) >> kshift) & 7);
@@ -124,6 +127,7 @@ struct ConvAFast {
             mask[rr] = mk;
         }
         cin = 0; dt = 0; dh = 0; dw = 0; tap = 0;
+        wcur = 0; wprev = 0;
     }
     __device__ __forceinline__ const unsigned short* src(int rr, int /*kt_unused*/) const {
         // uniform: offset of tap (dt,dh,dw) and of the cache frames relative to x
@@ -138,16 +142,39 @@ struct ConvAFast {
         }
         return ok ? ptr : zero;
     }
+    // K is walked (dt, dh, channel tile, dw) — dw INNERMOST, not in the weight's own (dt, dh, dw, channel) order: the kw taps of one row
+    // read the same input lines shifted by one position (ldc elements), so consecutive K tiles of the 32 workgroups sharing an L2 re-read
+    // what the tile before just fetched instead of coming back to it Cin/64 tiles (~4 MB of other traffic) later. The weight tile that
+    // belongs to the position is addressed through wk() (same products, another summation order).
     __device__ __forceinline__ void advance() {
+        wprev = wcur;
+        if (!dw_inner) {
+            wcur += BK;
+            cin += BK;
+            if (cin >= Cin) {
+                cin = 0;
+                if (++dw == kw) {
+                    dw = 0;
+                    if (++dh == kh) { dh = 0; ++dt; }
+                }
+            }
+            return;
+        }
+        if (++dw < kw) {
+            wcur += Cin;
+            return;
+        }
+        dw = 0;
+        wcur -= (kw - 1) * Cin;
         cin += BK;
+        wcur += BK;
         if (cin >= Cin) {
             cin = 0;
-            if (++dw == kw) {
-                dw = 0;
-                if (++dh == kh) { dh = 0; ++dt; }
-            }
+            wcur += (kw - 1) * Cin;           // = start of the next row of taps: ((dt*kh + dh + 1) * kw) * Cin
+            if (++dh == kh) { dh = 0; ++dt; }
         }
     }
+    __device__ __forceinline__ int wk(int /*kt*/, bool behind) const { return behind ? wprev : wcur; }
 };
 
 }  // namespace
@@ -198,6 +225,7 @@ extern "C" int yume_conv3d_cl(const void* x, const void* cache, int64_t ldc, int
         af.Tin = al.Tin; af.Hin = al.Hin; af.Win = al.Win; af.Cin = al.Cin;
         af.To = al.To; af.Ho = al.Ho; af.Wo = al.Wo; af.M = al.M;
         af.kt = kt; af.kh = kh; af.kw = kw; af.st = st; af.sh = sh; af.sw = sw; af.pt = pt; af.ph = ph; af.pw = pw; af.ups = 0;
+        { static const int ko = [] { const char* v = getenv("YUME_CONV_KORDER"); return v ? atoi(v) : 1; }(); af.dw_inner = ko != 0 && kw > 1; }
         switch (epi) {
             case YUME_EPI_BF16: return big ? launch256<YUME_EPI_BF16>(p, af, e, s, "conv3d_cl", 0) : launch<YUME_EPI_BF16>(p, af, e, s, "conv3d_cl");
             case YUME_EPI_F32: return big ? launch256<YUME_EPI_F32>(p, af, e, s, "conv3d_cl", 0) : launch<YUME_EPI_F32>(p, af, e, s, "conv3d_cl");

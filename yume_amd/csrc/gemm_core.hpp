@@ -80,6 +80,8 @@ struct PlainA {
     }
     __device__ __forceinline__ const unsigned short* src(int rr, int kt) const { return rowp[rr] + kt * BK; }
     __device__ __forceinline__ void advance() {}
+    // element offset inside a W row of K tile kt (a loader may walk K in its own order: conv3d.hip)
+    __device__ __forceinline__ int wk(int kt, bool /*behind*/) const { return kt * BK; }
 };
 
 __device__ __forceinline__ void stage_b(const unsigned short* __restrict__ W, int64_t ldw, int n0, int N, int k0,
@@ -254,7 +256,7 @@ __global__ __launch_bounds__(NTHR, 2) void gemm128_kernel(Problem p, ALoad al, E
     const int nk = p.K / BK;
     al.init(m0, tid);
     stage_a(al, 0, smem, wave);
-    stage_b(p.W, p.ldw, n0, p.N, 0, smem + TILE_BYTES, tid, wave);
+    stage_b(p.W, p.ldw, n0, p.N, al.wk(0, true), smem + TILE_BYTES, tid, wave);       // (the loader has moved on to tile 1)
 
     int cur = 0;
     for (int kt = 0; kt < nk; ++kt) {
@@ -265,7 +267,7 @@ __global__ __launch_bounds__(NTHR, 2) void gemm128_kernel(Problem p, ALoad al, E
         if (kt + 1 < nk) {
             char* nb = smem + (cur ^ 1) * STAGE_BYTES;
             stage_a(al, kt + 1, nb, wave);
-            stage_b(p.W, p.ldw, n0, p.N, (kt + 1) * BK, nb + TILE_BYTES, tid, wave);
+            stage_b(p.W, p.ldw, n0, p.N, al.wk(kt + 1, true), nb + TILE_BYTES, tid, wave);
         }
         const char* At = smem + cur * STAGE_BYTES;
         const char* Bt = At + TILE_BYTES;
@@ -327,10 +329,10 @@ __device__ __forceinline__ void stage_half_a(ALoad& al, int mh, int kt, char* ha
     }
 }
 
-__device__ __forceinline__ void stage_half_b(const unsigned short* const (&wrow)[4], int nh, int kt, char* half, int wave) {
+__device__ __forceinline__ void stage_half_b(const unsigned short* const (&wrow)[4], int nh, int koff, char* half, int wave) {
 #pragma unroll
     for (int r2 = 0; r2 < 2; ++r2) {
-        const unsigned short* g = wrow[nh * 2 + r2] + kt * BK;
+        const unsigned short* g = wrow[nh * 2 + r2] + koff;
         char* l = half + r2 * 8192 + wave * 1024;
         __builtin_amdgcn_global_load_lds((gbl_cvoid*)g, (lds_void*)l, 16, 0, 0);
     }
@@ -552,14 +554,15 @@ __device__ __forceinline__ void gemm256_mainloop(const Problem& p, ALoad& al, ch
     constexpr int OA0 = 0, OA1 = HALF_BYTES, OB0 = 2 * HALF_BYTES, OB1 = 3 * HALF_BYTES;
 
     // ---- prologue: issue order = steady-state order (A0, B1, A1, B0 of tile 0; A0, B1, A1 of tile 1) ----
+    // (W of K tile kt sits at element offset al.wk(kt, behind) of its row: `behind` = kt is the tile before the one the loader stands on)
     stage_half_a(al, 0, 0, s0 + OA0, wave);
-    stage_half_b(wrow, 1, 0, s0 + OB1, wave);
+    stage_half_b(wrow, 1, al.wk(0, false), s0 + OB1, wave);
     stage_half_a(al, 1, 0, s0 + OA1, wave);
     al.advance();
-    stage_half_b(wrow, 0, 0, s0 + OB0, wave);
+    stage_half_b(wrow, 0, al.wk(0, true), s0 + OB0, wave);
     if (nk > 1) {
         stage_half_a(al, 0, 1, s1 + OA0, wave);
-        stage_half_b(wrow, 1, 1, s1 + OB1, wave);
+        stage_half_b(wrow, 1, al.wk(1, false), s1 + OB1, wave);
         stage_half_a(al, 1, 1, s1 + OA1, wave);
         al.advance();
         asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
@@ -591,7 +594,7 @@ __device__ __forceinline__ void gemm256_mainloop(const Problem& p, ALoad& al, ch
         for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) a[mi][ks] = lds_frag(cs + OA0, arow + mi * 16, ks * 4 + lch);
-        if (t + 1 < nk) stage_half_b(wrow, 0, t + 1, ns + OB0, wave);
+        if (t + 1 < nk) stage_half_b(wrow, 0, al.wk(t + 1, true), ns + OB0, wave);
         YUME_PHASE_SYNC();
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
@@ -625,7 +628,7 @@ __device__ __forceinline__ void gemm256_mainloop(const Problem& p, ALoad& al, ch
         for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) a[mi][ks] = lds_frag(cs + OA1, arow + mi * 16, ks * 4 + lch);
-        if (t + 2 < nk) stage_half_b(wrow, 1, t + 2, cs + OB1, wave);
+        if (t + 2 < nk) stage_half_b(wrow, 1, al.wk(t + 2, false), cs + OB1, wave);
         YUME_PHASE_SYNC();
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
