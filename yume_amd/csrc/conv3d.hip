@@ -12,6 +12,7 @@
 // Conv2d 3x3 after nearest-exact x2, Conv2d 3x3 stride 2 after ZeroPad2d((0,1,0,1)), and 1x1x1.
 // Roofline: MFMA (bf16 dense); algorithmic work 2*M*Cout*Cin*kt*kh*kw flop per launch.
 #include "gemm_core.hpp"
+#include "conv_w4.hpp"
 
 using namespace gemm_core;
 
@@ -106,7 +107,7 @@ struct ConvAFast {
     // uniform state: position (dt, dh, cin, dw) of the K walk and the element offset of that K tile inside a weight row (and of the tile before)
     int cin, dt, dh, dw, tap;
     int wcur, wprev;
-    int dw_inner;     // 1 (default): walk K with dw innermost; 0 (env YUME_CONV_KORDER=0, A/B): the weight's own order
+    int k_order;      // 2 (default): K walked (dt, channel tile, dh, dw); 1: (dt, dh, channel tile, dw); 0: the weight's own order (env YUME_CONV_KORDER, A/B)
 
     __device__ __forceinline__ void init(int m0, int tid, int rpr = 32, int kshift = 0) {
         const int lc = (tid & 7) ^ (((tid >> 3) >> kshift) & 7);
@@ -142,13 +143,14 @@ struct ConvAFast {
         }
         return ok ? ptr : zero;
     }
-    // K is walked (dt, dh, channel tile, dw) — dw INNERMOST, not in the weight's own (dt, dh, dw, channel) order: the kw taps of one row
-    // read the same input lines shifted by one position (ldc elements), so consecutive K tiles of the 32 workgroups sharing an L2 re-read
-    // what the tile before just fetched instead of coming back to it Cin/64 tiles (~4 MB of other traffic) later. The weight tile that
-    // belongs to the position is addressed through wk() (same products, another summation order).
+    // K is NOT walked in the weight's own (dt, dh, dw, channel) order. order 2 (default): (dt, channel tile, dh, dw) — the kh*kw taps of
+    // one frame and one 64-channel slice read the same few input rows shifted by a position / a row, so the 32 workgroups sharing an L2
+    // re-read for 9 consecutive K tiles what the first of them fetched (working set: their ~15 rows x 128 B per position ~ 1.2 MB of the
+    // 4 MiB L2) instead of coming back to it Cin/64 tiles (4+ MB of other traffic) later. order 1: (dt, dh, channel tile, dw).
+    // The weight tile that belongs to the position is addressed through wk() (same products, another summation order).
     __device__ __forceinline__ void advance() {
         wprev = wcur;
-        if (!dw_inner) {
+        if (k_order == 0) {
             wcur += BK;
             cin += BK;
             if (cin >= Cin) {
@@ -166,12 +168,28 @@ struct ConvAFast {
         }
         dw = 0;
         wcur -= (kw - 1) * Cin;
+        if (k_order == 1) {
+            cin += BK;
+            wcur += BK;
+            if (cin >= Cin) {
+                cin = 0;
+                wcur += (kw - 1) * Cin;           // = start of the next row of taps: ((dt*kh + dh + 1) * kw) * Cin
+                if (++dh == kh) { dh = 0; ++dt; }
+            }
+            return;
+        }
+        if (++dh < kh) {
+            wcur += kw * Cin;
+            return;
+        }
+        dh = 0;
+        wcur -= (kh - 1) * kw * Cin;
         cin += BK;
         wcur += BK;
         if (cin >= Cin) {
             cin = 0;
-            wcur += (kw - 1) * Cin;           // = start of the next row of taps: ((dt*kh + dh + 1) * kw) * Cin
-            if (++dh == kh) { dh = 0; ++dt; }
+            ++dt;
+            wcur += (kh * kw - 1) * Cin;          // = ((dt + 1) * kh * kw) * Cin
         }
     }
     __device__ __forceinline__ int wk(int /*kt*/, bool behind) const { return behind ? wprev : wcur; }
@@ -219,13 +237,26 @@ extern "C" int yume_conv3d_cl(const void* x, const void* cache, int64_t ldc, int
     e.hw = (int)(Ho * Wo);
     hipStream_t s = (hipStream_t)stream;
     const bool big = use_256(p, variant, true);
+    {
+        // stride-1 convolutions over whole-tile frames: the one-wave-per-SIMD pipeline (conv_w4.hpp); YUME_CONV_W4=0 keeps the 8-wave kernel
+        gemm_w4::ConvW4 cv;
+        cv.x = al.x; cv.cache = al.cache; cv.ldc = ldc;
+        cv.Tin = (int)Tin; cv.Hin = (int)Hin; cv.Win = (int)Win; cv.Cin = (int)Cin; cv.To = (int)To; cv.Ho = (int)Ho; cv.Wo = (int)Wo;
+        cv.kt = kt; cv.kh = kh; cv.kw = kw; cv.pt = pt; cv.ph = ph; cv.pw = pw;
+        const int e2 = epi == YUME_CONV_EPI_ADD ? EPI_BF16_ADD : epi == YUME_CONV_EPI_TSPLIT ? EPI_BF16_TSPLIT : epi;
+        Problem p2 = p;
+        p2.tiles_m = (int)((M + 255) / 256);
+        p2.tiles_n = (int)((Cout + 255) / 256);
+        if (big && gemm_w4::conv_w4_applies(p2, cv, st, sh, sw, ups, e2) && (epi != YUME_CONV_EPI_ADD || (add != nullptr && (ldadd % 4) == 0)))
+            return gemm_w4::launch_conv_w4(e2, p, cv, e, s, "conv3d_cl");
+    }
     if ((Cin % BK) == 0 && !ups && kh * kw <= 32) {
         ConvAFast af = {};
         af.x = al.x; af.cache = al.cache; af.zero = al.zero; af.ldc = al.ldc;
         af.Tin = al.Tin; af.Hin = al.Hin; af.Win = al.Win; af.Cin = al.Cin;
         af.To = al.To; af.Ho = al.Ho; af.Wo = al.Wo; af.M = al.M;
         af.kt = kt; af.kh = kh; af.kw = kw; af.st = st; af.sh = sh; af.sw = sw; af.pt = pt; af.ph = ph; af.pw = pw; af.ups = 0;
-        { static const int ko = [] { const char* v = getenv("YUME_CONV_KORDER"); return v ? atoi(v) : 1; }(); af.dw_inner = ko != 0 && kw > 1; }
+        { static const int ko = [] { const char* v = getenv("YUME_CONV_KORDER"); return v ? atoi(v) : 2; }(); af.k_order = (ko == 0 || ko == 1) ? ko : 2; }
         switch (epi) {
             case YUME_EPI_BF16: return big ? launch256<YUME_EPI_BF16>(p, af, e, s, "conv3d_cl", 0) : launch<YUME_EPI_BF16>(p, af, e, s, "conv3d_cl");
             case YUME_EPI_F32: return big ? launch256<YUME_EPI_F32>(p, af, e, s, "conv3d_cl", 0) : launch<YUME_EPI_F32>(p, af, e, s, "conv3d_cl");

@@ -1,0 +1,205 @@
+// conv_w4.hpp — the implicit-GEMM convolution on the one-wave-per-SIMD pipeline of gemm_w4.hpp (r3).
+//
+// The 8-wave kernel's conv loader (conv3d.hip, ConvAFast) computes a 64-bit source pointer per row and per K tile — mask test, two selects,
+// a 64-bit add, for each of its 4 rows, in VALU instructions beside the MFMAs: its matrix pipe is 49 % busy on the dominant Wan2.2-decoder
+// convolution (r2 PMC) against 72 % of the same kernel on a dense GEMM. Here, for stride-1 convolutions whose frames are whole tiles
+// (Ho*Wo % 256 == 0; Cin % 64 == 0, no folded upsample):
+//   * a row's source offset is loop-invariant: va[j] = (ho*Win + wo) * ldc*2 + swizzled chunk, relative to the input FRAME the tap reads;
+//   * the tap is wave-uniform: the frame (x or the 2-frame causal cache) is a buffer descriptor in SGPRs, rebuilt when dt changes; the
+//     position inside the frame is the SGPR offset soff = (dh*Win + dw) * ldc*2 + channel tile (descriptor base = frame - (ph*Win + pw)*ldc*2);
+//   * a tap outside the image for a row (bit dh*kw+dw of the row's mask clear) is one v_cndmask: the lane's offset becomes 0xffffffff,
+//     beyond the descriptor's range, and the LDS-DMA writes zeros for it — no zero page, no pointer select; a missing cache is a
+//     descriptor of zero records;
+//   * K is walked (dt, channel tile, dh, dw) as in conv3d.hip (L2 reuse across the kh*kw taps); the weight tile of a position is W + wk.
+// Everything else — LDS images, fragment reads, gap plan, epilogues — is gemm_w4.hpp's.
+#pragma once
+#include "gemm_w4.hpp"
+
+namespace gemm_w4 {
+
+struct ConvW4 {
+    const unsigned short* x;       // [Tin, Hin, Win, ldc]
+    const unsigned short* cache;   // [2, Hin, Win, ldc] or nullptr
+    int64_t ldc;
+    int Tin, Hin, Win, Cin, To, Ho, Wo;
+    int kt, kh, kw, pt, ph, pw;
+};
+
+// wave-uniform walk of the K tiles (the tile to STAGE): order (dt, channel tile, dh, dw)
+struct ConvWalk {
+    int dt, dh, dw, cin;
+    int wk;               // element offset of the K tile inside a weight row
+    unsigned soff;        // byte offset of tap (dh, dw) + channel tile inside the frame
+};
+
+__device__ __forceinline__ void conv_set_frame(Ctx& c, const ConvW4& cv, int to, int dt) {
+    const int ti = to - cv.pt + dt;                                  // (stride 1)
+    const int64_t frame = (int64_t)cv.Hin * cv.Win * cv.ldc;         // elements
+    const unsigned short* base = ti >= 0 ? cv.x + (int64_t)ti * frame : cv.cache + (int64_t)(ti + 2) * frame;
+    const bool have = (ti >= 0 && ti < cv.Tin) || (ti < 0 && ti >= -2 && cv.cache != nullptr);
+    const uint64_t b = (uint64_t)(uintptr_t)base - (uint64_t)((int64_t)(cv.ph * cv.Win + cv.pw) * cv.ldc * 2);
+    i32x4 d;
+    d[0] = (int)(unsigned)(b & 0xffffffffu);
+    d[1] = (int)(unsigned)((b >> 32) & 0xffffu);                    // stride 0: raw buffer
+    d[2] = have ? 0x7fffffff : 0;                                    // num_records: every in-image offset passes, 0xffffffff never does
+    d[3] = 0x00020000;
+    c.srd = d;
+}
+
+__device__ __forceinline__ void conv_apply(Ctx& c, const ConvW4& cv, const ConvWalk& w, const char* pbw) {
+    c.soff = w.soff;
+    c.tapmask = 1u << (w.dh * cv.kw + w.dw);
+    c.pb = pbw + (int64_t)w.wk * 2;
+}
+
+// one step of the walk; returns true when dt changed (new frame descriptor)
+__device__ __forceinline__ bool conv_advance(ConvWalk& w, const ConvW4& cv) {
+    const unsigned ldc2 = (unsigned)cv.ldc * 2u;
+    if (++w.dw < cv.kw) {
+        w.wk += cv.Cin;
+        w.soff += ldc2;
+        return false;
+    }
+    w.dw = 0;
+    w.wk -= (cv.kw - 1) * cv.Cin;
+    w.soff -= (unsigned)(cv.kw - 1) * ldc2;
+    if (++w.dh < cv.kh) {
+        w.wk += cv.kw * cv.Cin;
+        w.soff += (unsigned)cv.Win * ldc2;
+        return false;
+    }
+    w.dh = 0;
+    w.wk -= (cv.kh - 1) * cv.kw * cv.Cin;
+    w.soff -= (unsigned)(cv.kh - 1) * (unsigned)cv.Win * ldc2;
+    w.cin += BK;
+    w.wk += BK;
+    w.soff += 2 * BK;
+    if (w.cin < cv.Cin) return false;
+    w.cin = 0;
+    w.soff -= 2u * (unsigned)cv.Cin;
+    w.wk += (cv.kh * cv.kw - 1) * cv.Cin;
+    ++w.dt;
+    return true;
+}
+
+template <bool DMA>
+__device__ __forceinline__ void conv_w4_loop(Ctx& c, const ConvW4& cv, ConvWalk& w, const char* pbw, int to, int t0, int t1, unsigned lbase) {
+    for (int t = t0; t < t1; ++t) {
+        w4_gaps<0, DMA, true, true>(c);
+        if constexpr (DMA) {
+            if (conv_advance(w, cv)) conv_set_frame(c, cv, to, w.dt);
+            conv_apply(c, cv, w, pbw);
+        }
+        c.lcur = lbase + (((t + 1) & 1) ? BUF_BYTES : 0);
+        c.ra1 ^= BUF_BYTES;
+        c.rb1 ^= BUF_BYTES;
+        c.ra0n ^= BUF_BYTES;
+        c.rb0n ^= BUF_BYTES;
+    }
+}
+
+__device__ __forceinline__ void conv_w4_mainloop(const Problem& p, const ConvW4& cv, char* smem, int m0, int n0) {
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+    Ctx c;
+    c.smem = smem;
+    const unsigned lbase = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem + wave * 1024;
+    c.lcur = lbase;
+    c.pa = nullptr;
+    const char* pbw = reinterpret_cast<const char*>(p.W + (int64_t)n0 * p.ldw);
+    const unsigned ldc2 = (unsigned)cv.ldc * 2u, ldw_b = (unsigned)p.ldw * 2u;
+    const int HW = cv.Ho * cv.Wo;
+    const int to = m0 / HW;                       // (a tile lies inside one output frame: HW % 256 == 0)
+    {
+        const int rl = 8 * wave + (lane >> 3);
+        const unsigned ch = (unsigned)(((lane & 7) ^ (rl & 7)) << 4);
+        const int nleft = p.N - 1 - n0;
+        const int r0 = m0 - to * HW;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int r = 32 * j + rl;
+            const int pos = r0 + r;
+            const int ho = pos / cv.Wo, wo = pos - ho * cv.Wo;
+            c.va[j] = (unsigned)(ho * cv.Win + wo) * ldc2 + ch;
+            const int hh = ho - cv.ph, ww = wo - cv.pw;
+            unsigned mk = 0;
+            for (int a = 0; a < cv.kh; ++a)
+                for (int b = 0; b < cv.kw; ++b)
+                    if (hh + a >= 0 && hh + a < cv.Hin && ww + b >= 0 && ww + b < cv.Win) mk |= 1u << (a * cv.kw + b);
+            c.mask[j] = mk;
+            c.vb[j] = (unsigned)min(r, nleft) * ldw_b + ch;
+        }
+    }
+    const unsigned sw0 = (unsigned)(((lane >> 4) ^ (lane & 7)) << 4), sw1 = (unsigned)(((4 | (lane >> 4)) ^ (lane & 7)) << 4);
+    const unsigned rowa = wr * 16384 + (lane & 15) * 128, rowb = OPER_BYTES + wc * 16384 + (lane & 15) * 128;
+    const int nk = p.K / BK;
+    ConvWalk w = {0, 0, 0, 0, 0, 0u};
+    conv_set_frame(c, cv, to, 0);
+    conv_apply(c, cv, w, pbw);
+    // ---- prologue: tiles 0 and 1 in flight, accumulators zeroed under their latency, F0(0) read ----
+    w4_stage_all<0, true>(c);
+    if (conv_advance(w, cv)) conv_set_frame(c, cv, to, w.dt);
+    conv_apply(c, cv, w, pbw);
+    c.lcur = lbase + BUF_BYTES;
+    w4_stage_all<0, true>(c);
+    if (conv_advance(w, cv)) conv_set_frame(c, cv, to, w.dt);
+    conv_apply(c, cv, w, pbw);
+    c.lcur = lbase;
+    acc_zero<0, 256>();
+    asm volatile("s_waitcnt vmcnt(16)\n\ts_barrier" ::: "memory");
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        c.fb[0][r] = w4_frag(c, rowb + sw0 + r * 2048);
+        c.fa[0][r] = w4_frag(c, rowa + sw0 + r * 2048);
+    }
+    c.ra1 = rowa + sw1;
+    c.rb1 = rowb + sw1;
+    c.ra0n = BUF_BYTES + rowa + sw0;
+    c.rb0n = BUF_BYTES + rowb + sw0;
+    conv_w4_loop<true>(c, cv, w, pbw, to, 0, nk - 2, lbase);
+    conv_w4_loop<false>(c, cv, w, pbw, to, nk - 2, nk, lbase);
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+}
+
+template <int UNUSED = 0>
+__global__ __launch_bounds__(NTHR_W4, 1) void conv_w4_kernel(Problem p, ConvW4 cv, Epilogue e, int epi) {
+    __shared__ __attribute__((aligned(16))) char smem[LDS_W4];
+    int start, count, m0, n0;
+    xcd_chunk(p.tiles_m * p.tiles_n, blockIdx.x & 7, start, count);
+    tile_origin(p, start + (blockIdx.x >> 3), m0, n0);
+    conv_w4_mainloop(p, cv, smem, m0, n0);
+    switch (epi) {
+        case YUME_EPI_F32: w4_epilogue<YUME_EPI_F32, true>(p, e, m0, n0, smem); break;
+        case EPI_BF16_ADD: w4_epilogue<EPI_BF16_ADD, true>(p, e, m0, n0, smem); break;
+        case EPI_BF16_TSPLIT: w4_epilogue<EPI_BF16_TSPLIT, true>(p, e, m0, n0, smem); break;
+        default: w4_epilogue<YUME_EPI_BF16, true>(p, e, m0, n0, smem); break;
+    }
+}
+
+// what the kernel takes (host): stride 1, no folded upsample, Cin in whole K tiles, frames in whole M tiles, >= 3 K tiles, 32-bit offsets
+inline bool conv_w4_applies(const Problem& p, const ConvW4& cv, int st, int sh, int sw, int ups, int epi) {
+    static const bool on = [] { const char* v = getenv("YUME_CONV_W4"); return !v || atoi(v) != 0; }();
+    if (!on || st != 1 || sh != 1 || sw != 1 || ups) return false;
+    if ((cv.Cin % BK) != 0 || ((int64_t)cv.Ho * cv.Wo) % 256 != 0 || cv.kh * cv.kw > 32 || p.K < 3 * BK) return false;
+    if ((int64_t)cv.Hin * cv.Win * cv.ldc * 2 + (int64_t)(cv.kh * cv.Win + cv.kw) * cv.ldc * 2 >= 0x7fffff00ll) return false;
+    if (255ll * p.ldw * 2 + 128 >= (1ll << 32)) return false;
+    if (cv.pt > 2 || (int64_t)p.tiles_m * p.tiles_n * 4 < 192) return false;          // too few tiles to fill the chip: the 128x128 kernel's job
+    if (epi == EPI_BF16_TSPLIT && (((p.N >> 1) % 256) != 0)) return false;
+    return epi == YUME_EPI_BF16 || epi == YUME_EPI_F32 || epi == EPI_BF16_ADD || epi == EPI_BF16_TSPLIT;
+}
+
+inline int launch_conv_w4(int epi, const Problem& p128, const ConvW4& cv, const Epilogue& e, hipStream_t st, const char* what) {
+    Problem p = p128;
+    p.tiles_m = (p.M + 255) / 256;
+    p.tiles_n = (p.N + 255) / 256;
+    p.group_m = g_group_m;
+    p.epi_direct = 0;
+    hipLaunchKernelGGL(conv_w4_kernel<0>, dim3((unsigned)(p.tiles_m * p.tiles_n)), dim3(NTHR_W4), 0, st, p, cv, e, epi);
+    YUME_CHECK_LAUNCH(what);
+    return YUME_OK;
+}
+
+}  // namespace gemm_w4

@@ -50,6 +50,15 @@ constexpr int LDS_W4 = 2 * BUF_BYTES;        // 128 KiB
                  "v_mfma_f32_16x16x32_bf16 a[%c6:%c7], %2, %3, a[%c6:%c7]"                                                                       \
                  ::"v"(X0), "v"(Y0), "v"(X1), "v"(Y1), "n"((T0) * 4), "n"((T0) * 4 + 3), "n"((T1) * 4), "n"((T1) * 4 + 3), "v"(voff), "s"(sbase),   \
                  "s"(lbase), "n"(loff) : "memory", "scc", W4_AGPRS)
+// ... the same with the source given by a buffer descriptor (conv_w4.hpp): address = srd.base + soff + voff[lane]; a lane whose voff is
+// beyond srd.num_records (0xffffffff = "this tap lies in the zero padding") is out of range and the LDS receives zeros for it
+#define W4_MFMA2_DMAB(T0, X0, Y0, T1, X1, Y1, voff, srd, soff, lbase, loff)                                                                           \
+    asm volatile("s_add_u32 m0, %11, %12\n\tv_mfma_f32_16x16x32_bf16 a[%c4:%c5], %0, %1, a[%c4:%c5]\n\tbuffer_load_dwordx4 %8, %9, %10 offen lds\n\t"  \
+                 "v_mfma_f32_16x16x32_bf16 a[%c6:%c7], %2, %3, a[%c6:%c7]"                                                                           \
+                 ::"v"(X0), "v"(Y0), "v"(X1), "v"(Y1), "n"((T0) * 4), "n"((T0) * 4 + 3), "n"((T1) * 4), "n"((T1) * 4 + 3), "v"(voff), "s"(srd),         \
+                 "s"(soff), "s"(lbase), "n"(loff) : "memory", "scc", W4_AGPRS)
+#define W4_DMAB(voff, srd, soff, lbase, loff) \
+    asm volatile("s_add_u32 m0, %3, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds" ::"v"(voff), "s"(srd), "s"(soff), "s"(lbase), "n"(loff) : "memory", "scc")
 // a stand-alone piece (prologue)
 #define W4_DMA(voff, sbase, lbase, loff) \
     asm volatile("s_add_u32 m0, %2, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lbase), "n"(loff) : "memory", "scc")
@@ -87,6 +96,11 @@ struct Ctx {
     const char* pa;                 // A tile base + K offset of the tile to stage next (wave-uniform)
     const char* pb;
     unsigned lcur;                  // LDS byte address of this wave's 1 KiB piece slot in the CURRENT tile's buffer (= the one tile t+2 is staged into)
+    // implicit-GEMM convolution (conv_w4.hpp): the A pieces of the tile to stage come from srd.base + soff + va[j] where the tap is
+    // inside the image for the row (bit `tapbit` of mask[j]), else from beyond the descriptor's range (-> zeros)
+    i32x4 srd;
+    unsigned soff, tapmask;
+    unsigned mask[8];
 };
 
 __device__ __forceinline__ bf16x8_t w4_frag(const Ctx& c, unsigned off) { return *reinterpret_cast<const bf16x8_t*>(c.smem + off); }
@@ -105,6 +119,8 @@ __device__ __forceinline__ bf16x8_t w4_frag(const Ctx& c, unsigned off) { return
 #define W4_PAIR(g) W4_MFMA2((g) & 63, W4_X(g), W4_Y(g), ((g) + 1) & 63, W4_X((g) + 1), W4_Y((g) + 1))
 #define W4_PAIR_DMA(g, voff, sbase, loff) \
     W4_MFMA2_DMA((g) & 63, W4_X(g), W4_Y(g), ((g) + 1) & 63, W4_X((g) + 1), W4_Y((g) + 1), voff, sbase, c.lcur, loff)
+#define W4_PAIR_DMAB(g, voff, loff) \
+    W4_MFMA2_DMAB((g) & 63, W4_X(g), W4_Y(g), ((g) + 1) & 63, W4_X((g) + 1), W4_Y((g) + 1), voff, c.srd, c.soff, c.lcur, loff)
 
 // ---- the gap plan of a K tile ------------------------------------------------------------------------------------------------------
 // The MFMAs go two per asm statement ("slot" k = MFMAs 2k, 2k+1): what rides inside a slot (a DMA piece, between its two MFMAs) or behind
@@ -149,14 +165,18 @@ constexpr int pieces_before_bar_b() {      // pieces of tile t+2 already issued 
 constexpr int P_F0_FIRST = P_BAR_B + 2;
 static_assert(P_F0_FIRST + 16 <= 64 && dma_pos(15) <= 63 && 15 < P_BAR_A && dma_pos(0) > P_BAR_A, "the plan must fit the 64 slots");
 
-template <int g, bool DMA, bool SWAP>
+__device__ __forceinline__ unsigned w4_conv_voff(const Ctx& c, int q) { return (c.mask[q] & c.tapmask) ? c.va[q] : 0xffffffffu; }
+
+template <int g, bool DMA, bool SWAP, bool CONV>
 __device__ __forceinline__ void w4_gaps(Ctx& c) {
     if constexpr (g < 128) {
         {
             constexpr int k = g >> 1, pos = k;                 // slot = plan position
             constexpr int q = (DMA && !(W4_ABLATE & 1)) ? piece_at(pos) : -1;
-            if constexpr (q >= 0 && q < 8) W4_PAIR_DMA(g, c.va[q & 7], c.pa, W4_PIECE_LOFF(q & 15));
-            else if constexpr (q >= 8) W4_PAIR_DMA(g, c.vb[q & 7], c.pb, W4_PIECE_LOFF(q & 15));
+            if constexpr (q >= 0 && q < 8) {
+                if constexpr (CONV) W4_PAIR_DMAB(g, w4_conv_voff(c, q & 7), W4_PIECE_LOFF(q & 15));
+                else W4_PAIR_DMA(g, c.va[q & 7], c.pa, W4_PIECE_LOFF(q & 15));
+            } else if constexpr (q >= 8) W4_PAIR_DMA(g, c.vb[q & 7], c.pb, W4_PIECE_LOFF(q & 15));
             else W4_PAIR(g);
             if constexpr (pos >= 0 && pos < 16 && !(W4_ABLATE & 2)) {     // F1(t): the W fragments first (segment 2's first 8 MFMAs need all eight)
                 if constexpr (pos < 8) c.fb[1][pos & 7] = w4_frag(c, c.rb1 + (pos & 7) * 2048);
@@ -181,17 +201,19 @@ __device__ __forceinline__ void w4_gaps(Ctx& c) {
                 if constexpr (r < 8) c.fb[0][r & 7] = w4_frag(c, c.rb0n + (r & 7) * 2048);
                 else c.fa[0][r & 7] = w4_frag(c, c.ra0n + (r & 7) * 2048);
             }
-            w4_gaps<g + 2, DMA, SWAP>(c);
+            w4_gaps<g + 2, DMA, SWAP, CONV>(c);
         }
     }
 }
 // the 16 pieces of one K tile, stand-alone (prologue)
-template <int q>
+template <int q, bool CONV>
 __device__ __forceinline__ void w4_stage_all(Ctx& c) {
     if constexpr (q < 16) {
-        if constexpr (q < 8) W4_DMA(c.va[q & 7], c.pa, c.lcur, W4_PIECE_LOFF(q));
-        else W4_DMA(c.vb[q & 7], c.pb, c.lcur, W4_PIECE_LOFF(q));
-        w4_stage_all<q + 1>(c);
+        if constexpr (q < 8) {
+            if constexpr (CONV) W4_DMAB(w4_conv_voff(c, q & 7), c.srd, c.soff, c.lcur, W4_PIECE_LOFF(q));
+            else W4_DMA(c.va[q & 7], c.pa, c.lcur, W4_PIECE_LOFF(q));
+        } else W4_DMA(c.vb[q & 7], c.pb, c.lcur, W4_PIECE_LOFF(q));
+        w4_stage_all<q + 1, CONV>(c);
     }
 }
 
@@ -241,7 +263,8 @@ __device__ __forceinline__ void w4_epilogue(const Problem& p, const Epilogue& e,
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wr = wave >> 1, wc = wave & 1;
     const int l15 = lane & 15, l4 = lane >> 4;
-    constexpr bool BF16_OUT = EPI == YUME_EPI_BF16 || EPI == YUME_EPI_BF16_GELU || EPI == YUME_EPI_BF16_GELU_ERF || EPI == YUME_EPI_BF16_SPLITT;
+    constexpr bool BF16_OUT = EPI == YUME_EPI_BF16 || EPI == YUME_EPI_BF16_GELU || EPI == YUME_EPI_BF16_GELU_ERF || EPI == YUME_EPI_BF16_SPLITT ||
+                              EPI == EPI_BF16_ADD || EPI == EPI_BF16_TSPLIT;
     if constexpr (!SWAP) {
         // K-major V^T tile: image rows = features n, columns = tokens m; whole rows of up to 256 tokens leave as 16-byte stores
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -268,18 +291,40 @@ __device__ __forceinline__ void w4_epilogue(const Problem& p, const Epilogue& e,
                 b[j] = (e.bias && n + 3 < p.N) ? *reinterpret_cast<const f32x4*>(e.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
             }
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            static_for<0, 64>([&](auto tt) {
-                constexpr int T = decltype(tt)::value, i = T >> 3, j = T & 7;
-                const f32x4 v = w4_act<EPI>(acc_tile<T>() + b[j]);
+            static_for<0, 8>([&](auto ii) {
+                constexpr int i = decltype(ii)::value;
                 const int r = wr * 128 + 16 * i + l15;
-                const int cc = wc * 128 + 16 * j + 4 * l4;
-                u32x2 o;
-                o[0] = pack_bf16x2(v[0], v[1]);
-                o[1] = pack_bf16x2(v[2], v[3]);
-                *reinterpret_cast<u32x2*>(smem + r * 512 + ((((cc >> 3) ^ r) & 31) << 4) + ((cc >> 2) & 1) * 8) = o;
+                u32x2 a2[8];
+                if constexpr (EPI == EPI_BF16_ADD) {              // the shortcut the conv output is added to: 8 loads in flight per row block
+                    const unsigned short* ap = e.add + (int64_t)min(m0 + r, p.M - 1) * e.ldadd + n0 + wc * 128 + 4 * l4;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) a2[j] = *reinterpret_cast<const u32x2*>(ap + 16 * j);
+                }
+                static_for<0, 8>([&](auto jj) {
+                    constexpr int j = decltype(jj)::value;
+                    f32x4 v = w4_act<EPI>(acc_tile<i * 8 + j>() + b[j]);
+                    if constexpr (EPI == EPI_BF16_ADD) {
+                        v[0] += bf16_to_f32((unsigned short)(a2[j][0] & 0xffffu));
+                        v[1] += bf16_to_f32((unsigned short)(a2[j][0] >> 16));
+                        v[2] += bf16_to_f32((unsigned short)(a2[j][1] & 0xffffu));
+                        v[3] += bf16_to_f32((unsigned short)(a2[j][1] >> 16));
+                    }
+                    const int cc = wc * 128 + 16 * j + 4 * l4;
+                    u32x2 o;
+                    o[0] = pack_bf16x2(v[0], v[1]);
+                    o[1] = pack_bf16x2(v[2], v[3]);
+                    *reinterpret_cast<u32x2*>(smem + r * 512 + ((((cc >> 3) ^ r) & 31) << 4) + ((cc >> 2) & 1) * 8) = o;
+                });
             });
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            w4_store_image(smem, reinterpret_cast<unsigned short*>(e.out), e.ldo, m0, min(256, p.M - m0), n0, min(256, p.N - n0));
+            if constexpr (EPI == EPI_BF16_TSPLIT) {
+                // out row m=(t,hw), col n=(j,c) -> out[((2t+j)*HW + hw), c]: a tile lies in one frame t and one channel half j (the caller checked
+                // HW % 256 == 0 and (N/2) % 256 == 0), so its rows stay consecutive
+                const int ch = p.N >> 1, jh = n0 >= ch ? 1 : 0, t = m0 / e.hw;
+                w4_store_image(smem, reinterpret_cast<unsigned short*>(e.out), e.ldo, m0 + (t + jh) * e.hw, min(256, p.M - m0), n0 - jh * ch, 256);
+            } else {
+                w4_store_image(smem, reinterpret_cast<unsigned short*>(e.out), e.ldo, m0, min(256, p.M - m0), n0, min(256, p.N - n0));
+            }
             return;
         }
         const bool whole = m0 + 256 <= p.M && n0 + 256 <= p.N;       // (workgroup-uniform)
@@ -326,7 +371,7 @@ __device__ __forceinline__ void w4_epilogue(const Problem& p, const Epilogue& e,
 template <bool DMA, bool SWAP>
 __device__ __forceinline__ void w4_loop(Ctx& c, int t0, int t1, unsigned lbase) {
     for (int t = t0; t < t1; ++t) {
-        w4_gaps<0, DMA, SWAP>(c);
+        w4_gaps<0, DMA, SWAP, false>(c);
         if constexpr (DMA) {
             c.pa += 128;
             c.pb += 128;
@@ -369,11 +414,11 @@ __device__ __forceinline__ void w4_mainloop(const Problem& p, const PlainA& al, 
     const unsigned rowa = wr * 16384 + (lane & 15) * 128, rowb = OPER_BYTES + wc * 16384 + (lane & 15) * 128;
     const int nk = p.K / BK;
     // ---- prologue: tiles 0 and 1 in flight, accumulators zeroed under their latency, F0(0) read ----
-    w4_stage_all<0>(c);
+    w4_stage_all<0, false>(c);
     c.pa += 128;
     c.pb += 128;
     c.lcur = lbase + BUF_BYTES;
-    w4_stage_all<0>(c);
+    w4_stage_all<0, false>(c);
     c.pa += 128;
     c.pb += 128;
     c.lcur = lbase;
@@ -397,6 +442,7 @@ __device__ __forceinline__ void w4_mainloop(const Problem& p, const PlainA& al, 
 
 // ONE kernel for every epilogue (the epilogue id is a kernel argument: the 128-MFMA loop body exists in 2 operand orders x {staging, not
 // staging} already, and instances of it that meet at a join made hipcc's register allocation spill through the accumulators)
+template <int UNUSED = 0>      // (a template so that the header can be included by several translation units)
 __global__ __launch_bounds__(NTHR_W4, 1) void gemm_w4_kernel(Problem p, PlainA al, Epilogue e, int epi) {
     __shared__ __attribute__((aligned(16))) char smem[LDS_W4];
     int start, count, m0, n0;
@@ -437,7 +483,7 @@ inline int launch_w4(int epi, const Problem& p128, const PlainA& al, const Epilo
     p.tiles_n = (p.N + 255) / 256;
     p.group_m = g_group_m;
     { static const int d = [] { const char* v = getenv("YUME_GEMM_EPI_DIRECT"); return v ? atoi(v) : 0; }(); p.epi_direct = d; }
-    hipLaunchKernelGGL(gemm_w4_kernel, dim3((unsigned)(p.tiles_m * p.tiles_n)), dim3(NTHR_W4), 0, st, p, al, e, epi);
+    hipLaunchKernelGGL(gemm_w4_kernel<0>, dim3((unsigned)(p.tiles_m * p.tiles_n)), dim3(NTHR_W4), 0, st, p, al, e, epi);
     YUME_CHECK_LAUNCH(what);
     return YUME_OK;
 }
