@@ -242,7 +242,7 @@ extern "C" int yume_conv3d_cl(const void* x, const void* cache, int64_t ldc, int
         gemm_w4::ConvW4 cv;
         cv.x = al.x; cv.cache = al.cache; cv.ldc = ldc;
         cv.Tin = (int)Tin; cv.Hin = (int)Hin; cv.Win = (int)Win; cv.Cin = (int)Cin; cv.To = (int)To; cv.Ho = (int)Ho; cv.Wo = (int)Wo;
-        cv.kt = kt; cv.kh = kh; cv.kw = kw; cv.pt = pt; cv.ph = ph; cv.pw = pw;
+        cv.kt = kt; cv.kh = kh; cv.kw = kw; cv.pt = pt; cv.ph = ph; cv.pw = pw; cv.ups = ups ? 1 : 0;
         const int e2 = epi == YUME_CONV_EPI_ADD ? EPI_BF16_ADD : epi == YUME_CONV_EPI_TSPLIT ? EPI_BF16_TSPLIT : epi;
         Problem p2 = p;
         p2.tiles_m = (int)((M + 255) / 256);

@@ -23,6 +23,7 @@ struct ConvW4 {
     int64_t ldc;
     int Tin, Hin, Win, Cin, To, Ho, Wo;
     int kt, kh, kw, pt, ph, pw;
+    int ups;                       // the conv reads the nearest-2x upsampled view of x (Ho = 2 Hin, Wo = 2 Win)
 };
 
 // wave-uniform walk of the K tiles (the tile to STAGE): order (dt, channel tile, dh, dw)
@@ -37,6 +38,7 @@ __device__ __forceinline__ void conv_set_frame(Ctx& c, const ConvW4& cv, int to,
     const int64_t frame = (int64_t)cv.Hin * cv.Win * cv.ldc;         // elements
     const unsigned short* base = ti >= 0 ? cv.x + (int64_t)ti * frame : cv.cache + (int64_t)(ti + 2) * frame;
     const bool have = (ti >= 0 && ti < cv.Tin) || (ti < 0 && ti >= -2 && cv.cache != nullptr);
+    // the descriptor starts (ph rows + pw positions) in front of the frame; the rows' offsets va[] are biased by the same amount
     const uint64_t b = (uint64_t)(uintptr_t)base - (uint64_t)((int64_t)(cv.ph * cv.Win + cv.pw) * cv.ldc * 2);
     i32x4 d;
     d[0] = (int)(unsigned)(b & 0xffffffffu);
@@ -46,10 +48,21 @@ __device__ __forceinline__ void conv_set_frame(Ctx& c, const ConvW4& cv, int to,
     c.srd = d;
 }
 
+template <int CONV>
 __device__ __forceinline__ void conv_apply(Ctx& c, const ConvW4& cv, const ConvWalk& w, const char* pbw) {
-    c.soff = w.soff;
     c.tapmask = 1u << (w.dh * cv.kw + w.dw);
     c.pb = pbw + (int64_t)w.wk * 2;
+    if constexpr (CONV == 2) {
+        // upsampled row 2a+e under tap dh (ph = 1) reads input row a + floor((e + dh - 1) / 2): e = 0: (-1, 0, 0), e = 1: (0, 0, +1); same for columns
+        const unsigned ldc2 = (unsigned)cv.ldc * 2u, rowb = (unsigned)cv.Win * ldc2;
+        c.soff = (unsigned)w.cin * 2u;
+        c.uh[0] = w.dh == 0 ? 0u - rowb : 0u;
+        c.uh[1] = w.dh == 2 ? rowb : 0u;
+        c.uw[0] = w.dw == 0 ? 0u - ldc2 : 0u;
+        c.uw[1] = w.dw == 2 ? ldc2 : 0u;
+    } else {
+        c.soff = w.soff;
+    }
 }
 
 // one step of the walk; returns true when dt changed (new frame descriptor)
@@ -82,13 +95,13 @@ __device__ __forceinline__ bool conv_advance(ConvWalk& w, const ConvW4& cv) {
     return true;
 }
 
-template <bool DMA>
+template <bool DMA, int CONV>
 __device__ __forceinline__ void conv_w4_loop(Ctx& c, const ConvW4& cv, ConvWalk& w, const char* pbw, int to, int t0, int t1, unsigned lbase) {
     for (int t = t0; t < t1; ++t) {
-        w4_gaps<0, DMA, true, true>(c);
+        w4_gaps<0, DMA, true, CONV>(c);
         if constexpr (DMA) {
             if (conv_advance(w, cv)) conv_set_frame(c, cv, to, w.dt);
-            conv_apply(c, cv, w, pbw);
+            conv_apply<CONV>(c, cv, w, pbw);
         }
         c.lcur = lbase + (((t + 1) & 1) ? BUF_BYTES : 0);
         c.ra1 ^= BUF_BYTES;
@@ -98,6 +111,7 @@ __device__ __forceinline__ void conv_w4_loop(Ctx& c, const ConvW4& cv, ConvWalk&
     }
 }
 
+template <int CONV>
 __device__ __forceinline__ void conv_w4_mainloop(const Problem& p, const ConvW4& cv, char* smem, int m0, int n0) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -122,12 +136,21 @@ __device__ __forceinline__ void conv_w4_mainloop(const Problem& p, const ConvW4&
             const int r = 32 * j + rl;
             const int pos = r0 + r;
             const int ho = pos / cv.Wo, wo = pos - ho * cv.Wo;
-            c.va[j] = (unsigned)(ho * cv.Win + wo) * ldc2 + ch;
             const int hh = ho - cv.ph, ww = wo - cv.pw;
             unsigned mk = 0;
-            for (int a = 0; a < cv.kh; ++a)
-                for (int b = 0; b < cv.kw; ++b)
-                    if (hh + a >= 0 && hh + a < cv.Hin && ww + b >= 0 && ww + b < cv.Win) mk |= 1u << (a * cv.kw + b);
+            if constexpr (CONV == 2) {
+                // offsets relative to the descriptor base = frame - (ph*Win + pw) positions (ph = pw = 1)
+                c.va[j] = (unsigned)(((ho >> 1) + cv.ph) * cv.Win + (wo >> 1) + cv.pw) * ldc2 + ch;
+                c.par[j] = (unsigned)((ho & 1) | ((wo & 1) << 1));
+                for (int a = 0; a < cv.kh; ++a)
+                    for (int b = 0; b < cv.kw; ++b)
+                        if (hh + a >= 0 && hh + a < 2 * cv.Hin && ww + b >= 0 && ww + b < 2 * cv.Win) mk |= 1u << (a * cv.kw + b);
+            } else {
+                c.va[j] = (unsigned)(ho * cv.Win + wo) * ldc2 + ch;
+                for (int a = 0; a < cv.kh; ++a)
+                    for (int b = 0; b < cv.kw; ++b)
+                        if (hh + a >= 0 && hh + a < cv.Hin && ww + b >= 0 && ww + b < cv.Win) mk |= 1u << (a * cv.kw + b);
+            }
             c.mask[j] = mk;
             c.vb[j] = (unsigned)min(r, nleft) * ldw_b + ch;
         }
@@ -137,15 +160,15 @@ __device__ __forceinline__ void conv_w4_mainloop(const Problem& p, const ConvW4&
     const int nk = p.K / BK;
     ConvWalk w = {0, 0, 0, 0, 0, 0u};
     conv_set_frame(c, cv, to, 0);
-    conv_apply(c, cv, w, pbw);
+    conv_apply<CONV>(c, cv, w, pbw);
     // ---- prologue: tiles 0 and 1 in flight, accumulators zeroed under their latency, F0(0) read ----
-    w4_stage_all<0, true>(c);
+    w4_stage_all<0, CONV>(c);
     if (conv_advance(w, cv)) conv_set_frame(c, cv, to, w.dt);
-    conv_apply(c, cv, w, pbw);
+    conv_apply<CONV>(c, cv, w, pbw);
     c.lcur = lbase + BUF_BYTES;
-    w4_stage_all<0, true>(c);
+    w4_stage_all<0, CONV>(c);
     if (conv_advance(w, cv)) conv_set_frame(c, cv, to, w.dt);
-    conv_apply(c, cv, w, pbw);
+    conv_apply<CONV>(c, cv, w, pbw);
     c.lcur = lbase;
     acc_zero<0, 256>();
     asm volatile("s_waitcnt vmcnt(16)\n\ts_barrier" ::: "memory");
@@ -158,8 +181,8 @@ __device__ __forceinline__ void conv_w4_mainloop(const Problem& p, const ConvW4&
     c.rb1 = rowb + sw1;
     c.ra0n = BUF_BYTES + rowa + sw0;
     c.rb0n = BUF_BYTES + rowb + sw0;
-    conv_w4_loop<true>(c, cv, w, pbw, to, 0, nk - 2, lbase);
-    conv_w4_loop<false>(c, cv, w, pbw, to, nk - 2, nk, lbase);
+    conv_w4_loop<true, CONV>(c, cv, w, pbw, to, 0, nk - 2, lbase);
+    conv_w4_loop<false, CONV>(c, cv, w, pbw, to, nk - 2, nk, lbase);
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
 }
@@ -170,7 +193,8 @@ __global__ __launch_bounds__(NTHR_W4, 1) void conv_w4_kernel(Problem p, ConvW4 c
     int start, count, m0, n0;
     xcd_chunk(p.tiles_m * p.tiles_n, blockIdx.x & 7, start, count);
     tile_origin(p, start + (blockIdx.x >> 3), m0, n0);
-    conv_w4_mainloop(p, cv, smem, m0, n0);
+    if (cv.ups) conv_w4_mainloop<2>(p, cv, smem, m0, n0);
+    else conv_w4_mainloop<1>(p, cv, smem, m0, n0);
     switch (epi) {
         case YUME_EPI_F32: w4_epilogue<YUME_EPI_F32, true>(p, e, m0, n0, smem); break;
         case EPI_BF16_ADD: w4_epilogue<EPI_BF16_ADD, true>(p, e, m0, n0, smem); break;
@@ -182,7 +206,8 @@ __global__ __launch_bounds__(NTHR_W4, 1) void conv_w4_kernel(Problem p, ConvW4 c
 // what the kernel takes (host): stride 1, no folded upsample, Cin in whole K tiles, frames in whole M tiles, >= 3 K tiles, 32-bit offsets
 inline bool conv_w4_applies(const Problem& p, const ConvW4& cv, int st, int sh, int sw, int ups, int epi) {
     static const bool on = [] { const char* v = getenv("YUME_CONV_W4"); return !v || atoi(v) != 0; }();
-    if (!on || st != 1 || sh != 1 || sw != 1 || ups) return false;
+    if (!on || st != 1 || sh != 1 || sw != 1) return false;
+    if (ups && (cv.kt != 1 || cv.kh != 3 || cv.kw != 3 || cv.ph != 1 || cv.pw != 1 || cv.pt != 0 || cv.Ho != 2 * cv.Hin || cv.Wo != 2 * cv.Win)) return false;
     if ((cv.Cin % BK) != 0 || ((int64_t)cv.Ho * cv.Wo) % 256 != 0 || cv.kh * cv.kw > 32 || p.K < 3 * BK) return false;
     if ((int64_t)cv.Hin * cv.Win * cv.ldc * 2 + (int64_t)(cv.kh * cv.Win + cv.kw) * cv.ldc * 2 >= 0x7fffff00ll) return false;
     if (255ll * p.ldw * 2 + 128 >= (1ll << 32)) return false;

@@ -101,6 +101,10 @@ struct Ctx {
     i32x4 srd;
     unsigned soff, tapmask;
     unsigned mask[8];
+    // ... with the nearest-2x upsample folded in (CONV = 2): the source of output (2a+e, 2b+f) under tap (dh, dw) is input row a + dH[e], column
+    // b + dW[f] (each -1, 0 or +1 by the tap): par[j] = e | f << 1 of the row, uh / uw = the two byte offsets of the current tap
+    unsigned par[8];
+    unsigned uh[2], uw[2];
 };
 
 __device__ __forceinline__ bf16x8_t w4_frag(const Ctx& c, unsigned off) { return *reinterpret_cast<const bf16x8_t*>(c.smem + off); }
@@ -165,16 +169,22 @@ constexpr int pieces_before_bar_b() {      // pieces of tile t+2 already issued 
 constexpr int P_F0_FIRST = P_BAR_B + 2;
 static_assert(P_F0_FIRST + 16 <= 64 && dma_pos(15) <= 63 && 15 < P_BAR_A && dma_pos(0) > P_BAR_A, "the plan must fit the 64 slots");
 
-__device__ __forceinline__ unsigned w4_conv_voff(const Ctx& c, int q) { return (c.mask[q] & c.tapmask) ? c.va[q] : 0xffffffffu; }
+template <int CONV>
+__device__ __forceinline__ unsigned w4_conv_voff(const Ctx& c, int q) {
+    unsigned v = c.va[q];
+    if constexpr (CONV == 2) v += ((c.par[q] & 1u) ? c.uh[1] : c.uh[0]) + ((c.par[q] & 2u) ? c.uw[1] : c.uw[0]);
+    return (c.mask[q] & c.tapmask) ? v : 0xffffffffu;
+}
 
-template <int g, bool DMA, bool SWAP, bool CONV>
+// CONV: 0 = dense GEMM (A by pointer), 1 = implicit-GEMM convolution (A by frame descriptor, conv_w4.hpp), 2 = ... with a folded 2x upsample
+template <int g, bool DMA, bool SWAP, int CONV>
 __device__ __forceinline__ void w4_gaps(Ctx& c) {
     if constexpr (g < 128) {
         {
             constexpr int k = g >> 1, pos = k;                 // slot = plan position
             constexpr int q = (DMA && !(W4_ABLATE & 1)) ? piece_at(pos) : -1;
             if constexpr (q >= 0 && q < 8) {
-                if constexpr (CONV) W4_PAIR_DMAB(g, w4_conv_voff(c, q & 7), W4_PIECE_LOFF(q & 15));
+                if constexpr (CONV != 0) W4_PAIR_DMAB(g, w4_conv_voff<CONV>(c, q & 7), W4_PIECE_LOFF(q & 15));
                 else W4_PAIR_DMA(g, c.va[q & 7], c.pa, W4_PIECE_LOFF(q & 15));
             } else if constexpr (q >= 8) W4_PAIR_DMA(g, c.vb[q & 7], c.pb, W4_PIECE_LOFF(q & 15));
             else W4_PAIR(g);
@@ -206,11 +216,11 @@ __device__ __forceinline__ void w4_gaps(Ctx& c) {
     }
 }
 // the 16 pieces of one K tile, stand-alone (prologue)
-template <int q, bool CONV>
+template <int q, int CONV>
 __device__ __forceinline__ void w4_stage_all(Ctx& c) {
     if constexpr (q < 16) {
         if constexpr (q < 8) {
-            if constexpr (CONV) W4_DMAB(w4_conv_voff(c, q & 7), c.srd, c.soff, c.lcur, W4_PIECE_LOFF(q));
+            if constexpr (CONV != 0) W4_DMAB(w4_conv_voff<CONV>(c, q & 7), c.srd, c.soff, c.lcur, W4_PIECE_LOFF(q));
             else W4_DMA(c.va[q & 7], c.pa, c.lcur, W4_PIECE_LOFF(q));
         } else W4_DMA(c.vb[q & 7], c.pb, c.lcur, W4_PIECE_LOFF(q));
         w4_stage_all<q + 1, CONV>(c);
@@ -371,7 +381,7 @@ __device__ __forceinline__ void w4_epilogue(const Problem& p, const Epilogue& e,
 template <bool DMA, bool SWAP>
 __device__ __forceinline__ void w4_loop(Ctx& c, int t0, int t1, unsigned lbase) {
     for (int t = t0; t < t1; ++t) {
-        w4_gaps<0, DMA, SWAP, false>(c);
+        w4_gaps<0, DMA, SWAP, 0>(c);
         if constexpr (DMA) {
             c.pa += 128;
             c.pb += 128;
@@ -414,11 +424,11 @@ __device__ __forceinline__ void w4_mainloop(const Problem& p, const PlainA& al, 
     const unsigned rowa = wr * 16384 + (lane & 15) * 128, rowb = OPER_BYTES + wc * 16384 + (lane & 15) * 128;
     const int nk = p.K / BK;
     // ---- prologue: tiles 0 and 1 in flight, accumulators zeroed under their latency, F0(0) read ----
-    w4_stage_all<0, false>(c);
+    w4_stage_all<0, 0>(c);
     c.pa += 128;
     c.pb += 128;
     c.lcur = lbase + BUF_BYTES;
-    w4_stage_all<0, false>(c);
+    w4_stage_all<0, 0>(c);
     c.pa += 128;
     c.pb += 128;
     c.lcur = lbase;
