@@ -11,13 +11,7 @@ from conftest import ROOT
 
 def test_owned_agprs_are_untouched_by_the_compiler():
     from yume_amd import build
-    src = os.path.join(build.CSRC, "attn_fwd7.hip")
-    with tempfile.TemporaryDirectory() as td:
-        out = os.path.join(td, "a7.s")
-        cmd = [build._hipcc()] + build.FLAGS + build.EXTRA_FLAGS.get("attn_fwd7.hip", []) + \
-              ["-I", build.INCLUDE, "--cuda-device-only", "-S", src, "-o", out]
-        subprocess.run(cmd, check=True, capture_output=True, text=True)
-        txt = open(out).read()
+    txt = build.device_asm("attn_fwd7.hip")          # the assembly of the library's own build (kept next to the objects)
     body = txt[txt.index("attn_fwd_kernel_v7"):]
     inasm, bad = False, []
     for line in body.split("\n"):

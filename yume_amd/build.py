@@ -59,7 +59,9 @@ def build_library(force=False, verbose=True):
 
     def compile_one(src):
         obj = os.path.join(objdir, os.path.basename(src)[:-4] + ".o")
-        cmd = [hipcc] + FLAGS + EXTRA_FLAGS.get(os.path.basename(src), []) + ["-I", INCLUDE, "-c", src, "-o", obj]
+        # -save-temps=obj: the device assembly (obj/<name>-hip-amdgcn-amd-amdhsa-gfx950.s) stays next to the object; the ISA audits of the
+        # hand-scheduled kernels (tests/test_attn7_isa.py, tests/test_gemm_w4_isa.py) read it instead of compiling the file again
+        cmd = [hipcc] + FLAGS + EXTRA_FLAGS.get(os.path.basename(src), []) + ["-I", INCLUDE, "-save-temps=obj", "-c", src, "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")
@@ -78,6 +80,15 @@ def build_library(force=False, verbose=True):
     if verbose:
         print(f"[yume_amd.build] built {LIBPATH}")
     return LIBPATH
+
+
+def device_asm(src_name):
+    """Text of the gfx950 assembly hipcc produced for csrc/<src_name> in the current build (built first if it is stale)."""
+    build_library(verbose=False)
+    path = os.path.join(LIBDIR, "obj", src_name[:-4] + f"-hip-amdgcn-amd-amdhsa-{ARCH}.s")
+    if not os.path.exists(path):      # an object directory from a build without -save-temps
+        build_library(force=True, verbose=False)
+    return open(path).read()
 
 
 if __name__ == "__main__":
