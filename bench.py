@@ -45,18 +45,23 @@ def flops_fwd_5b(L, C=3072, ffn=14336, n=30, Lc=512, cin=48, cout=48):
     return n * blk + 2 * L * (cin * 4) * C + 2 * 512 * (4096 * C + C * C) + 2 * L * (256 * C + C * C + 6 * C * C) + 2 * L * C * 4 * cout
 
 
+PMC_GROUP_FILE = "r3_pmc_gemm_block_shapes.csv"      # tools/run_pmc_gemm.sh: ONE GEMM of the block per process -> one row set per group
 PMC_FILES = ("r2_pmc_traffic_v3.csv", "r2_pmc_dominant_kernels.csv", "r1_pmc_dominant_kernels.csv")
-# only kernels the PMC workload (tools/pmc_probe.py) launches at ONE shape: its gemm256_kernel<3> rows average the o-projection and
-# ffn.2 launches, so the residual-epilogue GEMMs carry no per-launch traffic figure
-PMC_KERNEL_OF_GROUP = {"attn_self": ("attn_fwd_kernel_v7", "attn_combine_kernel"), "gemm_ffn0": ("gemm256_kernel<1", "gemm128_kernel<1"),
-                       "gemm_qkv": ("gemm256_kernel<4", "gemm128_kernel<4")}
+PMC_KERNEL_OF_GROUP = {"attn_self": ("attn_fwd_kernel_v7", "attn_combine_kernel")}
 
 
 def pmc_traffic_bytes(group):
-    """HBM/fabric bytes per launch of a kernel group from the committed rocprofv3 PMC passes (profiles/*_pmc_dominant_kernels.csv:
-    FETCH_SIZE and WRITE_SIZE in KiB; FETCH_SIZE doubled per the gfx950 calibration in MI355X_MICROARCH.md, confirmed on the
-    adaLN kernel: 2*FETCH = 4*L*C exactly). None when no pass of that kernel is committed."""
+    """HBM/fabric bytes per launch of a kernel group from the committed rocprofv3 PMC passes (profiles/: FETCH_SIZE and WRITE_SIZE in KiB;
+    FETCH_SIZE doubled per the gfx950 calibration in MI355X_MICROARCH.md, confirmed on the adaLN kernel: 2*FETCH = 4*L*C exactly).
+    The GEMM groups come from per-shape passes (one GEMM of the block, with its epilogue, per profiled process; a group's kernels —
+    the 256x256 launch and the 128x128 launch on its row remainder — are summed). None when no pass of that kernel is committed."""
     import csv
+    try:
+        rows = [r for r in csv.DictReader(open(os.path.join(ROOT, "profiles", PMC_GROUP_FILE))) if r["group"] == group]
+        if rows:
+            return sum((2.0 * float(r["FETCH_SIZE"]) + float(r["WRITE_SIZE"])) * 1024.0 for r in rows)
+    except Exception:  # noqa: BLE001
+        pass
     names = PMC_KERNEL_OF_GROUP.get(group)
     if not names:
         return None
@@ -191,11 +196,11 @@ def kernel_rooflines(prof, steps, ms_per_step, L, cfg, Lc=512):
         "attn_self": ("mfma", 4.0 * L * L * D * H, f"self-attention {L}x{L}x{H} heads, d={D}: attn_fwd_kernel_v7 (+ attn_combine_kernel for the "
                       "query blocks of the partial last round, timed together as one yume_attn_fwd_ws call)"),
         "attn_cross": ("mfma", 4.0 * L * Lc * D * H, f"cross-attention {L}x{Lc}x{H} heads: attn_fwd_kernel_v2"),
-        "gemm_qkv": ("mfma", 2.0 * L * 3 * C * C, f"QKV GEMM {L}x{3 * C}x{C}, transposed-V epilogue"),
+        "gemm_qkv": ("mfma", 2.0 * L * 3 * C * C, f"QKV GEMM {L}x{3 * C}x{C}, transposed-V epilogue (gemm_w4_kernel + gemm128_kernel on the row remainder)"),
         "gemm_o": ("mfma", 2.0 * L * C * C, f"o-proj GEMM {L}x{C}x{C}, gate*y + residual epilogue"),
         "gemm_cross_q": ("mfma", 2.0 * L * C * C, f"cross q GEMM {L}x{C}x{C}"),
         "gemm_cross_o": ("mfma", 2.0 * L * C * C, f"cross o-proj GEMM {L}x{C}x{C}, residual epilogue"),
-        "gemm_ffn0": ("mfma", 2.0 * L * Fd * C, f"ffn.0 GEMM {L}x{Fd}x{C} + bias + GELU (gemm256_kernel + gemm128_kernel on the row remainder)"),
+        "gemm_ffn0": ("mfma", 2.0 * L * Fd * C, f"ffn.0 GEMM {L}x{Fd}x{C} + bias + GELU (gemm_w4_kernel + gemm128_kernel on the row remainder)"),
         "gemm_ffn2": ("mfma", 2.0 * L * C * Fd, f"ffn.2 GEMM {L}x{C}x{Fd}, gate*y + residual epilogue"),
         "adaln": ("hbm", 6.0 * L * C, "LayerNorm + modulate: 4*L*C read + 2*L*C written"),
         "rmsnorm_rope": ("hbm", None, "RMSNorm (+RoPE) in place on q|k / cross q (2 B read + 2 B written per element)"),

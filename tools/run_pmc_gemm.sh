@@ -1,6 +1,6 @@
 #!/bin/bash
 # rocprofv3 PMC passes (counters in their own runs, kernel trace only) of the GEMM kernels, one shape per process.
-# usage (on the GPU box): bash tools/run_pmc_gemm.sh <outdir> "M N K [epi]" ...
+# usage (on the GPU box): bash tools/run_pmc_gemm.sh <outdir> qkv o cross_q cross_o ffn0 ffn2 | "M N K [variant]" ...     (PMC_WITH_LIB=1 adds the vendor library)
 export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$1; shift

@@ -67,6 +67,12 @@ def build_library(force=False, verbose=True):
             raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")
         if verbose and r.stderr.strip():
             sys.stderr.write(r.stderr)
+        stem = os.path.join(objdir, os.path.basename(src)[:-4])
+        for f in os.listdir(objdir):          # of the temporaries only the device assembly is kept
+            full = os.path.join(objdir, f)
+            if full.startswith(stem + "-") or full.startswith(stem + ".hip-"):
+                if not f.endswith(f"-hip-amdgcn-amd-amdhsa-{ARCH}.s"):
+                    os.remove(full)
         return obj
 
     with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
