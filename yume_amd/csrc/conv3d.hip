@@ -13,6 +13,7 @@
 // Roofline: MFMA (bf16 dense); algorithmic work 2*M*Cout*Cin*kt*kh*kw flop per launch.
 #include "gemm_core.hpp"
 #include "conv_w4.hpp"
+#include "conv_halo.hpp"
 
 using namespace gemm_core;
 
@@ -237,6 +238,20 @@ extern "C" int yume_conv3d_cl(const void* x, const void* cache, int64_t ldc, int
     e.hw = (int)(Ho * Wo);
     hipStream_t s = (hipStream_t)stream;
     const bool big = use_256(p, variant, true);
+    if (conv_halo::applies(Cin, Cout, kt, kh, kw, st, sh, sw, pt, ph, pw, ups, Hin, Win, Ho, Wo, ldc, ldo, ldw, epi)) {
+        // few output channels at full resolution (the decoder's head): halo tile in LDS, the 9 in-plane taps out of it (conv_halo.hpp)
+        conv_halo::Params hp;
+        hp.x = al.x; hp.cache = al.cache; hp.w = (const unsigned short*)W; hp.bias = bias; hp.out = (unsigned short*)out;
+        hp.ldc = ldc; hp.ldw = ldw; hp.ldo = ldo;
+        hp.Tin = (int)Tin; hp.H = (int)Hin; hp.W = (int)Win; hp.C = (int)Cin; hp.To = (int)To; hp.cout = (int)Cout;
+        hp.tiles_w = (int)((Wo + conv_halo::TW - 1) / conv_halo::TW);
+        hp.tiles_h = (int)((Ho + conv_halo::TH - 1) / conv_halo::TH);
+        const int64_t nt = To * hp.tiles_h * hp.tiles_w;
+        YUME_REQUIRE(nt < (1ll << 31), "conv3d_cl: too many tiles");
+        hipLaunchKernelGGL(conv_halo::conv_halo16_kernel<0>, dim3((unsigned)nt), dim3(256), 0, s, hp);
+        YUME_CHECK_LAUNCH("conv3d_cl");
+        return YUME_OK;
+    }
     {
         // stride-1 convolutions over whole-tile frames: the one-wave-per-SIMD pipeline (conv_w4.hpp); YUME_CONV_W4=0 keeps the 8-wave kernel
         gemm_w4::ConvW4 cv;
