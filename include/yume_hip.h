@@ -81,9 +81,12 @@ int yume_adaln_modulate(const float* x, int64_t ldx, int64_t T, int64_t C, float
  *                      (row stride ldt >= M) — the K-major V^T image the attention kernel consumes.
  *                      n_split must be a multiple of 128.
  * bias: fp32 [N] or NULL.
- * variant: 0 = automatic — the 256x256-tile kernel once its tiles fill the chip, else the 128x128-tile kernel; when the
- *   256x256 tiling would leave a last round of tiles at most ~1/3 full, whole rounds of M-tiles go to the 256x256 kernel and
- *   the remaining rows to the 128x128 kernel (two launches inside this call). 1 = 128x128 kernel, 2 = 256x256 kernel.
+ * variant: 0 = automatic — a 256x256-tile kernel once its tiles fill the chip (r3: the one-wave-per-SIMD kernel of csrc/gemm_w4.hpp
+ *   where it applies: K >= 192, the six epilogues above; env YUME_GEMM_W4=0 keeps the 8-wave kernel), else the 128x128-tile kernel;
+ *   when the 256x256 tiling would leave a last round of tiles at most ~1/3 full, whole rounds of M-tiles go to the 256x256 kernel
+ *   and the remaining rows to the 128x128 kernel (two launches inside this call). 1 = 128x128 kernel, 2 = the 8-wave 256x256
+ *   kernel, 3 = the one-wave-per-SIMD 256x256 kernel (as 2 where it does not apply). All variants compute the same products in
+ *   fp32; they differ in summation order only.
  */
 enum {
     YUME_EPI_BF16 = 0,
@@ -225,6 +228,11 @@ int yume_transpose_bf16(const void* in, int in_bf16, int64_t ldi, int64_t rows, 
  *   chunk, [2,Hin,Win,ldc]) or zeros when cache is NULL; hi = ho*sh + dh - ph, wi likewise, zero outside the frame;
  *   ups != 0: (hi, wi) index a nearest-2x-upsampled view of the input (hi>>1, wi>>1).
  * W: bf16 [Cout, ldw], ldw >= kt*kh*kw*Cin rounded up to 64, zero padded. zero_page: >= 16 zero bytes on the device.
+ * Kernel choice (r3, inside the call; every path computes the same sum in fp32, in its own order): stride-1 convolutions whose frames
+ *   are whole 256-position tiles with Cin % 64 == 0 (plain or with the folded upsample) run on the one-wave-per-SIMD pipeline
+ *   (csrc/conv_w4.hpp; env YUME_CONV_W4=0: the 8-wave kernel); a causal 3x3x3 conv with Cout <= 16 on frames of >= 64 Ki positions
+ *   (the decoder head) on the halo-tile kernel (csrc/conv_halo.hpp; YUME_CONV_HALO=0); everything else on the GEMM kernels with a
+ *   gathering A loader. YUME_CONV_KORDER=0/1/2 selects the K walk of that loader (default 2: dt, channel tile, dh, dw).
  * epi: YUME_EPI_BF16 (bias), YUME_EPI_F32, YUME_CONV_EPI_ADD (out = acc + bias + add[m, co], add bf16 [M, ldadd] —
  *      the ResidualBlock skip, vae2_2.py:239), YUME_CONV_EPI_TSPLIT (upsample3d time_conv, vae2_2.py:145-153:
  *      channel halves of frame t become frames 2t and 2t+1: out[((2t+j)*Ho*Wo + hw), c] for co = j*Cout/2 + c).

@@ -252,3 +252,83 @@ def test_tiled_decode_overlap_on_the_device_vae():
     (a0, a1), (b0, b1) = _tile_spans(z.shape[3], 2, 1)
     left = vae.decode([z[:, -2:, :, a0:a1]])[0]
     assert torch.equal(til[..., :b0 * 16], left[..., :b0 * 16])          # columns only the first band covers
+
+
+# ---- r3: the shapes that route to the one-wave-per-SIMD conv pipeline (conv_w4.hpp) and the halo kernel (conv_halo.hpp), directly against
+# torch's fp32 convolution on the host: N edge tiles (Cout < 256), the fused skip, zero padding on every border, the causal cache and
+# its absence, the folded upsample, the time_conv interleave, the few-channel head
+@pytest.mark.parametrize("Cin,Cout,T,H,W,with_cache", [(64, 192, 4, 112, 112, True), (128, 256, 2, 160, 160, False), (192, 320, 4, 112, 112, True)])
+def test_conv_w4_3x3x3_and_skip_vs_torch(Cin, Cout, T, H, W, with_cache):
+    assert (H * W) % 256 == 0 and T * H * W >= 192 * 256            # whole-tile frames, enough tiles: conv_w4_kernel takes it
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    x = rnd(Cin, T, H, W, seed=11).bfloat16().float()
+    cache = rnd(Cin, 2, H, W, seed=12).bfloat16().float() if with_cache else None
+    w = (rnd(Cout, Cin, 3, 3, 3, seed=13) * (27 * Cin) ** -0.5).bfloat16().float()
+    b = rnd(Cout, seed=14) * 0.1
+    xin = torch.cat([cache, x], dim=1) if with_cache else F.pad(x, (0, 0, 0, 0, 2, 0))
+    want = F.conv3d(F.pad(xin.unsqueeze(0), (1, 1, 1, 1)), w, b)[0]
+    out = torch.empty(T, H, W, Cout, dtype=torch.bfloat16, device=DEV)
+    V.conv3d_cl(cl(x), cl(cache) if with_cache else None, pack_w(w), b.to(DEV), Cout, (3, 3, 3), (1, 1, 1), (2, 1, 1), False, out,
+                V.EPI_BF16, zero_page=zero_page())
+    got = ncthw(out)
+    assert (got - want).abs().max() <= 2.0 ** -7 * want.abs().max() + 1e-3
+    assert rel_l2(got, want) < 5e-3
+    # borders: every face of the volume separately (zero padding / the cache)
+    for sl in ((slice(None), 0), (slice(None), -1), (slice(None), slice(None), 0), (slice(None), slice(None), -1),
+               (slice(None), slice(None), slice(None), 0), (slice(None), slice(None), slice(None), -1)):
+        assert rel_l2(got[sl], want[sl]) < 5e-3
+    skip = rnd(Cout, T, H, W, seed=15).bfloat16().float()
+    V.conv3d_cl(cl(x), cl(cache) if with_cache else None, pack_w(w), b.to(DEV), Cout, (3, 3, 3), (1, 1, 1), (2, 1, 1), False, out,
+                V.EPI_ADD, add=cl(skip), zero_page=zero_page())
+    assert rel_l2(ncthw(out), want + skip) < 5e-3
+
+
+def test_conv_w4_folded_upsample_and_time_conv_vs_torch():
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    C, Co, T, H, W = 64, 128, 2, 80, 80                              # 160 x 160 output frames = 100 tiles each
+    x = rnd(C, T, H, W, seed=21).bfloat16().float()
+    w = (rnd(Co, C, 3, 3, seed=22) * (9 * C) ** -0.5).bfloat16().float()
+    b = rnd(Co, seed=23) * 0.1
+    up = F.interpolate(x.permute(1, 0, 2, 3), scale_factor=(2.0, 2.0), mode="nearest-exact")
+    want = F.conv2d(up, w, b, padding=1).permute(1, 0, 2, 3)
+    out = torch.empty(T, 2 * H, 2 * W, Co, dtype=torch.bfloat16, device=DEV)
+    V.conv3d_cl(cl(x), None, pack_w(w.unsqueeze(2)), b.to(DEV), Co, (1, 3, 3), (1, 1, 1), (0, 1, 1), True, out, V.EPI_BF16,
+                zero_page=zero_page())
+    got = ncthw(out)
+    assert rel_l2(got, want) < 5e-3
+    assert rel_l2(got[:, :, 0], want[:, :, 0]) < 5e-3 and rel_l2(got[:, :, :, -1], want[:, :, :, -1]) < 5e-3
+    # upsample3d time_conv: C -> 2C with both channel halves whole 256-wide tiles, frames interleaved (vae2_2.py:145-153)
+    C, T, H, W = 256, 2, 112, 112
+    x = rnd(C, T, H, W, seed=24).bfloat16().float()
+    cache = rnd(C, 2, H, W, seed=25).bfloat16().float()
+    w = (rnd(2 * C, C, 3, 1, 1, seed=26) * (3 * C) ** -0.5).bfloat16().float()
+    b = rnd(2 * C, seed=27) * 0.1
+    y = F.conv3d(torch.cat([cache, x], 1).unsqueeze(0), w, b)[0].reshape(2, C, T, H, W)
+    want = torch.stack((y[0], y[1]), dim=2).reshape(C, 2 * T, H, W)
+    out = torch.empty(2 * T, H, W, C, dtype=torch.bfloat16, device=DEV)
+    V.conv3d_cl(cl(x), cl(cache), pack_w(w), b.to(DEV), 2 * C, (3, 1, 1), (1, 1, 1), (2, 0, 0), False, out, V.EPI_TSPLIT,
+                zero_page=zero_page())
+    assert rel_l2(ncthw(out), want) < 5e-3
+
+
+@pytest.mark.parametrize("with_cache", [False, True])
+def test_conv_halo_head_vs_torch(with_cache):
+    """256 x 256 frames, 64 / 128 input channels, 12 output channels in a 16-channel row: conv_halo16_kernel (ragged right / bottom tiles too)."""
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    for Cin, H, W in ((64, 256, 256), (128, 258, 300)):
+        T, Cout = 2, 12
+        x = rnd(Cin, T, H, W, seed=31).bfloat16().float()
+        cache = rnd(Cin, 2, H, W, seed=32).bfloat16().float() if with_cache else None
+        w = (rnd(Cout, Cin, 3, 3, 3, seed=33) * (27 * Cin) ** -0.5).bfloat16().float()
+        b = rnd(Cout, seed=34) * 0.1
+        xin = torch.cat([cache, x], dim=1) if with_cache else F.pad(x, (0, 0, 0, 0, 2, 0))
+        want = F.conv3d(F.pad(xin.unsqueeze(0), (1, 1, 1, 1)), w, b)[0]
+        out = torch.full((T, H, W, 16), 7.0, dtype=torch.bfloat16, device=DEV)
+        V.conv3d_cl(cl(x), cl(cache) if with_cache else None, pack_w(w), b.to(DEV), Cout, (3, 3, 3), (1, 1, 1), (2, 1, 1), False, out,
+                    V.EPI_BF16, zero_page=zero_page())
+        got = ncthw(out)
+        assert rel_l2(got[:Cout], want) < 5e-3, (Cin, H, W)
+        assert (got[Cout:] == 0).all()                               # the channel padding of the row holds zeros
+        for sl in ((slice(None, Cout), 0), (slice(None, Cout), slice(None), 0), (slice(None, Cout), slice(None), -1),
+                   (slice(None, Cout), slice(None), slice(None), 0), (slice(None, Cout), slice(None), slice(None), -1)):
+            assert rel_l2(got[sl], want[(slice(None),) + sl[1:]]) < 5e-3

@@ -306,9 +306,11 @@ __device__ __forceinline__ void w4_epilogue(const Problem& p, const Epilogue& e,
                 const int r = wr * 128 + 16 * i + l15;
                 u32x2 a2[8];
                 if constexpr (EPI == EPI_BF16_ADD) {              // the shortcut the conv output is added to: 8 loads in flight per row block
-                    const unsigned short* ap = e.add + (int64_t)min(m0 + r, p.M - 1) * e.ldadd + n0 + wc * 128 + 4 * l4;
+                    const int nl = n0 + wc * 128 + 4 * l4;
+                    const unsigned short* ap = e.add + (int64_t)min(m0 + r, p.M - 1) * e.ldadd + nl;
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) a2[j] = *reinterpret_cast<const u32x2*>(ap + 16 * j);
+                    for (int j = 0; j < 8; ++j)          // (columns beyond N — an N edge tile — are never stored: nothing is read for them)
+                        a2[j] = nl + 16 * j + 3 < p.N ? *reinterpret_cast<const u32x2*>(ap + 16 * j) : u32x2{0u, 0u};
                 }
                 static_for<0, 8>([&](auto jj) {
                     constexpr int j = decltype(jj)::value;
