@@ -67,7 +67,7 @@ def gemm_ref(a, w, bias):
 
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 256, 192), (1, 128, 64), (129, 384, 3072), (1000, 192, 1536),
                                    (257, 512, 1280), (2048, 1024, 512), (700, 520, 4096)])
-@pytest.mark.parametrize("variant", [1, 2])
+@pytest.mark.parametrize("variant", [1, 2, 3])      # 128x128, 8-wave 256x256, one-wave-per-SIMD 256x256 (gemm_w4.hpp)
 def test_gemm_bf16_plain_and_f32(M, N, K, variant):
     a, w, bias = rnd(M, K, seed=1, dtype=torch.bfloat16), rnd(N, K, seed=2, scale=K ** -0.5, dtype=torch.bfloat16), rnd(N, seed=3)
     want = gemm_ref(a, w, bias)
@@ -89,7 +89,7 @@ def test_gemm_bf16_plain_and_f32(M, N, K, variant):
     assert (oe.cpu().double() - we).abs().max() <= 2.0 ** -7 * we.abs().max() + 1e-5
 
 
-@pytest.mark.parametrize("variant", [1, 2])
+@pytest.mark.parametrize("variant", [1, 2, 3])      # 128x128, 8-wave 256x256, one-wave-per-SIMD 256x256 (gemm_w4.hpp)
 def test_gemm_detects_transpose_and_permutation(variant):
     """A = I-like and asymmetric W: a swapped row/col in the C-write or a k-permutation mismatch cannot pass."""
     M, N, K = 256, 256, 256
@@ -101,7 +101,7 @@ def test_gemm_detects_transpose_and_permutation(variant):
 
 
 @pytest.mark.parametrize("M,N,K,R", [(300, 512, 512, 2), (130, 3072, 1024, 1)])
-@pytest.mark.parametrize("variant", [1, 2])
+@pytest.mark.parametrize("variant", [1, 2, 3])      # 128x128, 8-wave 256x256, one-wave-per-SIMD 256x256 (gemm_w4.hpp)
 def test_gemm_resid_gate(M, N, K, R, variant):
     a, w, bias = rnd(M, K, seed=1, dtype=torch.bfloat16), rnd(N, K, seed=2, scale=K ** -0.5, dtype=torch.bfloat16), rnd(N, seed=3)
     x = rnd(M, N, seed=4)
@@ -119,7 +119,7 @@ def test_gemm_resid_gate(M, N, K, R, variant):
 
 
 @pytest.mark.parametrize("M", [64, 301, 516])
-@pytest.mark.parametrize("variant", [1, 2])
+@pytest.mark.parametrize("variant", [1, 2, 3])      # 128x128, 8-wave 256x256, one-wave-per-SIMD 256x256 (gemm_w4.hpp)
 def test_gemm_split_transposed(M, variant):
     C, K = 256, 512
     N = 3 * C
