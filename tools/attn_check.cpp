@@ -1,5 +1,5 @@
 // attn_check — standalone (no torch) correctness + timing harness for yume_attn_fwd variants.
-//   build:  hipcc -O2 --offload-arch=gfx950 tools/attn_check.cpp -o tools/attn_check -Lyume_amd/lib -lyume_hip -Wl,-rpath,'$ORIGIN/../yume_amd/lib'
+//   build:  hipcc -O2 --offload-arch=gfx950 tools/attn_check.cpp -o tools/attn_check -ldl      (NOT linked against the library: a second copy loaded first would capture the --lib build's calls)
 //   run:    tools/attn_check [variants...]        (default variants: 7 263 256 4 2 0; v + 256 = v | YUME_ATTN_Q_PRESCALED: the harness
 //           hands the kernel q' = bf16(q * scale * log2 e) and the references take exp2(q' . k))
 // Small shapes are checked against an fp64 exact-softmax reference computed on the host (test infrastructure, like oracle/);
@@ -160,14 +160,16 @@ int main(int argc, char** argv) {
     bool timing_only = false;
     int big_spike = 1;
     int one[3] = {0, 0, 0};
+    const char* trace = nullptr;      // --trace file: dump the per-workgroup time stamps of an experiment build (csrc/trace.hpp) after a --one run
     for (int i = 1; i < argc; ++i) {
         if (!strcmp(argv[i], "--lib")) lib = argv[++i];
         else if (!strcmp(argv[i], "--timing")) timing_only = true;
         else if (!strcmp(argv[i], "--nospike")) big_spike = 0;
+        else if (!strcmp(argv[i], "--trace")) trace = argv[++i];
         else if (!strcmp(argv[i], "--one")) { one[0] = atoi(argv[i + 1]); one[1] = atoi(argv[i + 2]); one[2] = atoi(argv[i + 3]); i += 3; timing_only = true; }
         else variants.push_back(atoi(argv[i]));
     }
-    void* hnd = dlopen(lib, RTLD_NOW);
+    void* hnd = dlopen(lib, RTLD_NOW | RTLD_LOCAL | RTLD_DEEPBIND);
     if (!hnd) { printf("dlopen %s: %s\n", lib, dlerror()); return 2; }
     p_attn = (attn_fn)dlsym(hnd, "yume_attn_fwd_ws"); p_ws = (ws_fn)dlsym(hnd, "yume_attn_workspace_bytes"); p_err = (err_fn)dlsym(hnd, "yume_last_error");
     printf("library %s\n", lib);
@@ -203,6 +205,16 @@ int main(int argc, char** argv) {
         for (int v : variants) {
             std::vector<uint16_t> out;
             for (int i = 0; i < 3; ++i) run(p, v, 0, out);
+        }
+        if (trace) {
+            typedef int (*trace_fn)(void*, long long);
+            trace_fn rd = (trace_fn)dlsym(hnd, "yume_debug_trace_read");
+            if (!rd) { printf("--trace: %s is not a -DYUME_TRACE build\n", lib); return 2; }
+            std::vector<unsigned long long> t(32768 * 8);
+            HC(hipDeviceSynchronize());
+            if (rd(t.data(), (long long)t.size() * 8)) { printf("trace read failed\n"); return 2; }
+            FILE* f = fopen(trace, "wb"); fwrite(t.data(), 8, t.size(), f); fclose(f);
+            printf("trace written to %s\n", trace);
         }
         drop(p);
         return 0;

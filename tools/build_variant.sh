@@ -9,5 +9,5 @@ extra=""; [ "$src" = attn_fwd7.hip ] && extra="-fno-slp-vectorize"
 /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=fast -Wno-unused-result -DNDEBUG $extra "$@" -I $root/include \
     -c $root/yume_amd/csrc/$src -o $root/yume_amd/lib/exp/${src%.hip}_$tag.o
 objs=$(ls $root/yume_amd/lib/obj/*.o | grep -v "/${src%.hip}.o")
-/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o $root/yume_amd/lib/exp/libyume_hip_$tag.so $objs $root/yume_amd/lib/exp/${src%.hip}_$tag.o
+/opt/rocm/bin/hipcc -shared -fPIC -Wl,-Bsymbolic --offload-arch=gfx950 -o $root/yume_amd/lib/exp/libyume_hip_$tag.so $objs $root/yume_amd/lib/exp/${src%.hip}_$tag.o
 echo built $root/yume_amd/lib/exp/libyume_hip_$tag.so

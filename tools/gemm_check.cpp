@@ -130,18 +130,22 @@ int main(int argc, char** argv) {
     bool timing_only = false, quick = false, expm = false;
     std::vector<int> variants = {2, 3};        // 2 = 8-wave 256x256 kernel, 3 = one-wave-per-SIMD 256x256 kernel (gemm_w4.hpp), 0 = automatic
     int reps = 2;
+    const char* trace = nullptr;      // --trace file (with --one): dump the per-workgroup time stamps of an experiment build (csrc/trace.hpp)
+    long long one[5] = {0, 0, 0, 0, 0};
     for (int i = 1; i < argc; ++i) {
         if (!strcmp(argv[i], "--lib")) lib = argv[++i];
         else if (!strcmp(argv[i], "--timing")) timing_only = true;
         else if (!strcmp(argv[i], "--quick")) { timing_only = true; quick = true; }     // the 5B shapes + 8192^3, the listed variants interleaved
         else if (!strcmp(argv[i], "--exp")) { timing_only = true; expm = true; }         // experiment builds (bf16 epilogue only): the block's shapes with a plain epilogue
         else if (!strcmp(argv[i], "--reps")) reps = atoi(argv[++i]);
+        else if (!strcmp(argv[i], "--trace")) trace = argv[++i];
+        else if (!strcmp(argv[i], "--one")) { for (int j = 0; j < 5; ++j) one[j] = atoll(argv[++i]); timing_only = true; }      // M N K epi row_idx_tables
         else if (!strcmp(argv[i], "--variants")) {
             variants.clear();
             for (char* t = strtok(argv[++i], ","); t; t = strtok(nullptr, ",")) variants.push_back(atoi(t));
         }
     }
-    void* hnd = dlopen(lib, RTLD_NOW);
+    void* hnd = dlopen(lib, RTLD_NOW | RTLD_LOCAL | RTLD_DEEPBIND);
     if (!hnd) { printf("dlopen %s: %s\n", lib, dlerror()); return 2; }
     p_gemm = (gemm_fn)dlsym(hnd, "yume_gemm_bf16"); p_err = (err_fn)dlsym(hnd, "yume_last_error");
     const char* mode = getenv("YUME_GEMM_MODE");
@@ -161,6 +165,21 @@ int main(int argc, char** argv) {
     const Case big[] = {{9460, 9216, 3072, YUME_EPI_BF16_SPLITT, 0}, {9460, 3072, 3072, YUME_EPI_RESID, 2}, {9460, 3072, 3072, YUME_EPI_RESID, 0},
                         {9460, 3072, 3072, YUME_EPI_BF16, 0}, {9460, 14336, 3072, YUME_EPI_BF16_GELU, 0}, {9460, 3072, 14336, YUME_EPI_RESID, 2},
                         {8192, 8192, 8192, YUME_EPI_BF16, 0}, {27810, 5120, 5120, YUME_EPI_RESID, 1}, {27810, 13824, 5120, YUME_EPI_BF16_GELU, 0}};
+    if (one[0]) {
+        const Case c = {(int)one[0], (int)one[1], (int)one[2], (int)one[3], (int)one[4]};
+        fails += run_case(c, variants, reps, false, true);
+        if (trace) {
+            typedef int (*trace_fn)(void*, long long);
+            trace_fn rd = (trace_fn)dlsym(hnd, "yume_debug_trace_read");
+            if (!rd) { printf("--trace: %s is not a -DYUME_TRACE build\n", lib); return 2; }
+            std::vector<unsigned long long> t(32768 * 8);
+            hipDeviceSynchronize();
+            if (rd(t.data(), (long long)t.size() * 8)) { printf("trace read failed\n"); return 2; }
+            FILE* f = fopen(trace, "wb"); fwrite(t.data(), 8, t.size(), f); fclose(f);
+            printf("trace written to %s\n", trace);
+        }
+        return fails ? 1 : 0;
+    }
     if (expm) {
         const Case ex[] = {{9460, 3072, 3072, YUME_EPI_BF16, 0}, {9460, 14336, 3072, YUME_EPI_BF16, 0}, {9460, 3072, 14336, YUME_EPI_BF16, 0}, {8192, 8192, 8192, YUME_EPI_BF16, 0}};
         for (auto& c : ex) fails += run_case(c, variants, reps, false, true);

@@ -29,6 +29,9 @@ def _hipcc():
     raise RuntimeError("hipcc not found")
 
 
+LINK_FLAGS = ["-Wl,-Bsymbolic"]
+
+
 def sources():
     return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
 
@@ -43,6 +46,7 @@ def _fingerprint():
                 h.update(fh.read())
     h.update(" ".join(FLAGS).encode())
     h.update(repr(sorted(EXTRA_FLAGS.items())).encode())
+    h.update(" ".join(LINK_FLAGS).encode())
     return h.hexdigest()
 
 
@@ -77,7 +81,9 @@ def build_library(force=False, verbose=True):
 
     with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
         objs = list(ex.map(compile_one, sources()))
-    cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIBPATH] + objs
+    # -Bsymbolic: calls between the library's own translation units bind inside it (an experiment build of the library loaded next to
+    # the product one — tools/*_check --lib — must run its own kernels, not the first-loaded library's)
+    cmd = [hipcc, "-shared", "-fPIC"] + LINK_FLAGS + [f"--offload-arch={ARCH}", "-o", LIBPATH] + objs
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")

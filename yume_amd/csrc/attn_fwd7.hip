@@ -39,6 +39,7 @@
 // Roofline: MFMA bf16 dense; algorithmic work 4*Lq*Lk*128 flop per head.
 #include "common.hpp"
 #include "attn_args.hpp"
+#include "trace.hpp"
 #include <type_traits>
 
 namespace {
@@ -588,6 +589,7 @@ __device__ __forceinline__ void run_keys(const AttnArgs& p, const Ctx& cx, const
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     NOP_PAD();
+    TRACE_STAMP(3);      // (experiment builds, trace.hpp: prologue done / steady loop entered / steady loop left)
 
     u32x4 ring[RD];
     // S_A(t0), then S_B(t0) beside softmax_A(t0)
@@ -610,6 +612,7 @@ __device__ __forceinline__ void run_keys(const AttnArgs& p, const Ctx& cx, const
             const int64_t kstep = (int64_t)KT * dp.krow;
             const char* kg = dp.kbase + (int64_t)(t + 4) * kstep;
             const char* vg = dp.vbase + (int64_t)(t + 3) * KT * 2;
+            TRACE_STAMP(4);
 #pragma unroll 1
             for (; t + 7 < tsteady; t += 4) {        // t % 4 == 1; the four calls issue tiles up to t + 7 (all full, all in range)
                 steady7<1, FAST>(cx, dp, kg, vg, kstep, A, B, ring);
@@ -617,6 +620,7 @@ __device__ __forceinline__ void run_keys(const AttnArgs& p, const Ctx& cx, const
                 steady7<3, FAST>(cx, dp, kg, vg, kstep, A, B, ring);
                 steady7<0, FAST>(cx, dp, kg, vg, kstep, A, B, ring);
             }
+            TRACE_STAMP(5);
         } else {
             if (ragged && t + 1 >= last) general7<FAST, true>(cx, dp, p, t, t0, t1, nt, ragged, tid, A, B, ring);
             else general7<FAST, false>(cx, dp, p, t, t0, t1, nt, ragged, tid, A, B, ring);
@@ -649,6 +653,7 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_kernel_v7(AttnArgs p) {
     const int hi = lane >> 5;
     const int ql = lane & 31;
     const int nt = (p.Lk + KT - 1) / KT;
+    TRACE_STAMP(0);
     // block -> (head, query block[, key range]): XCD x (= blockIdx % 8) owns heads x, x+8, ...; its whole blocks come first, then the
     // key-range pieces of the blocks >= tail_qb (hardware dispatches block ids in order: the pieces fill the last, partial round)
     int h, qb, sp = 0, nsp = 1;
@@ -708,6 +713,7 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_kernel_v7(AttnArgs p) {
         run_keys<false, true>(p, cx, dp, A, B, q0, ql, h, hi, t0, t1, nt, tid);
     }
 
+    TRACE_STAMP(1);
     if (nsp > 1) {
         const int row0 = p.q_lo + p.tail_qb * QB7;
         const int64_t rows = p.Lq - row0;
@@ -717,6 +723,7 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_kernel_v7(AttnArgs p) {
         store_block<OA>(p, A, q0 + ql, h, hi);
         store_block<OB>(p, B, q0 + 32 + ql, h, hi);
     }
+    TRACE_STAMP(2);
 }
 
 }  // namespace

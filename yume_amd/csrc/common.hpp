@@ -77,4 +77,16 @@ __device__ __forceinline__ float gelu_tanh(float x) {
     const float e = __builtin_amdgcn_exp2f(x * (c1 * x2 + c0));            // exp(-2u)
     return x * __builtin_amdgcn_rcpf(e + 1.0f);
 }
+// two elements at a time on the packed fp32 ALU (v_pk_mul / v_pk_fma / v_pk_add: one issue slot for both) — the same operations in the same
+// order as gelu_tanh, so the same bits; for epilogues that run with the matrix pipe idle and are bound by VALU issue
+__device__ __forceinline__ f32x2_t gelu_tanh2(f32x2_t x) {
+    const float k0 = -2.0f * 0.7978845608028654f * 1.4426950408889634f, k1 = k0 * 0.044715f;
+    const f32x2_t c0 = {k0, k0}, c1 = {k1, k1}, one = {1.0f, 1.0f};
+    const f32x2_t x2 = x * x;
+    const f32x2_t u = x * (c1 * x2 + c0);
+    const f32x2_t e = {__builtin_amdgcn_exp2f(u[0]), __builtin_amdgcn_exp2f(u[1])};
+    const f32x2_t d = e + one;
+    const f32x2_t r = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+    return x * r;
+}
 __device__ __forceinline__ float silu(float x) { return x / (1.0f + __expf(-x)); }

@@ -24,6 +24,7 @@
 // Roofline: MFMA bf16 dense; 2*M*N*K flop per launch.
 #pragma once
 #include "gemm_core.hpp"
+#include "trace.hpp"
 
 namespace gemm_w4 {
 using namespace gemm_core;
@@ -233,8 +234,8 @@ __device__ __forceinline__ void w4_stage_all(Ctx& c) {
 template <int EPI>
 __device__ __forceinline__ f32x4 w4_act(f32x4 v) {
     if (EPI == YUME_EPI_BF16_GELU) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) v[q] = gelu_tanh(v[q]);
+        const f32x2_t lo = gelu_tanh2(f32x2_t{v[0], v[1]}), hi = gelu_tanh2(f32x2_t{v[2], v[3]});
+        v = f32x4{lo[0], lo[1], hi[0], hi[1]};
     }
     if (EPI == YUME_EPI_BF16_GELU_ERF) {
 #pragma unroll
@@ -245,26 +246,73 @@ __device__ __forceinline__ f32x4 w4_act(f32x4 v) {
 
 // bf16 tile image in LDS: [256 rows][512 B], 16-byte chunk c of row r at chunk c ^ (r & 31); stored as whole rows (1 KiB per wave store).
 // rows = output rows of `dst` (tokens m for row-major outputs, features n for the K-major V^T), cols the contiguous index.
+// A wave stores rows 64 wave .. +63, two per instruction (lanes 0-31 / 32-63): 8 image reads in flight, then their 8 stores; the per-row
+// work is one XOR with a literal (the swizzle) and a 64-bit add (two rows down).
 __device__ __forceinline__ void w4_store_image(char* smem, unsigned short* dst, int64_t ld, int row0, int rows_valid, int col0, int cols_valid) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    unsigned short* out = dst + col0 + (lane & 31) * 8;
-    const bool col_ok = (lane & 31) * 8 + 8 <= cols_valid;
-    const int col_left = cols_valid - (lane & 31) * 8;          // elements of this lane's chunk inside the matrix (ragged last chunk)
-#pragma unroll 8
+    const int l31 = lane & 31, rh = lane >> 5;
+    if (cols_valid == 256) {                                       // (workgroup-uniform) whole rows: every tile but the N / M-edge ones of a ragged matrix
+        // row r = 64 wave + 2 it + rh: r & 31 = 2 (it & 15) + rh, so the chunk is (l31 ^ rh) ^ 2 (it & 15)
+        const unsigned lrow = (unsigned)((wave * 64 + rh) * 512), lch = (unsigned)((l31 ^ rh) << 4);
+        char* o = reinterpret_cast<char*>(dst + col0 + l31 * 8) + (int64_t)(row0 + wave * 64 + rh) * ld * 2;
+        const int64_t step = ld * 4;                               // two rows down
+        const int rleft = rows_valid - wave * 64 - rh;             // this lane's row 2 it + .. is inside the matrix iff 2 it < rleft
+        auto rows = [&](auto pred) {
+            constexpr bool PRED = decltype(pred)::value;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                u32x4 d[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int it = g * 8 + u;
+                    d[u] = *reinterpret_cast<const u32x4*>(smem + lrow + it * 1024 + (lch ^ (unsigned)(32 * (it & 15))));
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int it = g * 8 + u;
+                    if (!PRED || 2 * it < rleft) *reinterpret_cast<u32x4*>(o + it * step) = d[u];
+                }
+            }
+        };
+        if (rows_valid == 256) rows(std::false_type{});            // (workgroup-uniform)
+        else rows(std::true_type{});
+        return;
+    }
+    unsigned short* out = dst + col0 + l31 * 8;
+    const int col_left = cols_valid - l31 * 8;                     // elements of this lane's chunk inside the matrix (ragged last chunk)
+#pragma unroll 2
     for (int it = 0; it < 32; ++it) {
-        const int r = wave * 64 + it * 2 + (lane >> 5);
-        const u32x4 d = *reinterpret_cast<const u32x4*>(smem + r * 512 + ((((lane & 31) ^ r) & 31) << 4));
-        if (r < rows_valid) {
+        const int r = wave * 64 + it * 2 + rh;
+        const u32x4 d = *reinterpret_cast<const u32x4*>(smem + r * 512 + (((l31 ^ r) & 31) << 4));
+        if (r < rows_valid && col_left > 0) {
             unsigned short* o = out + (int64_t)(row0 + r) * ld;
-            if (col_ok) {
+            if (col_left >= 8) {
                 *reinterpret_cast<u32x4*>(o) = d;
-            } else if (col_left > 0) {
-                const unsigned short* s = reinterpret_cast<const unsigned short*>(&d);
-                for (int q = 0; q < col_left; ++q) o[q] = s[q];
+            } else {
+#pragma unroll
+                for (int q = 0; q < 7; ++q)
+                    if (q < col_left) o[q] = (unsigned short)(d[q >> 1] >> (16 * (q & 1)));
             }
         }
     }
+}
+
+// Image addresses of a lane's 64 accumulator tiles without per-tile arithmetic. A tile (a, b) — a = its 16-row block of the image, b = its
+// 16-column block — puts the lane's 4 consecutive columns at row R = 128 rsel + 16 a + l15, chunk (16 csel + 2 b + (l4 >> 1)) ^ (R & 31),
+// half l4 & 1. With R & 31 = 16 (a & 1) + l15 the XOR splits into 16 (csel ^ (a & 1)) and (2 b) ^ ((l4 >> 1) ^ l15): one VGPR per b for even
+// a, one for odd a, and a * 8192 in the instruction's offset field.
+struct ImageOff { unsigned e[8], o[8]; };
+__device__ __forceinline__ ImageOff w4_image_offsets(int rsel, int csel, int l15, int l4) {
+    ImageOff r;
+    const unsigned base = (unsigned)((rsel * 128 + l15) * 512 + (l4 & 1) * 8), ux = (unsigned)(((l4 >> 1) ^ l15) << 4);
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+        const unsigned ob = (unsigned)(32 * b) ^ ux;
+        r.e[b] = base + 256u * (unsigned)csel + ob;
+        r.o[b] = base + 256u * (unsigned)(csel ^ 1) + ob;
+    }
+    return r;
 }
 
 template <int EPI, bool SWAP>
@@ -277,17 +325,18 @@ __device__ __forceinline__ void w4_epilogue(const Problem& p, const Epilogue& e,
                               EPI == EPI_BF16_ADD || EPI == EPI_BF16_TSPLIT;
     if constexpr (!SWAP) {
         // K-major V^T tile: image rows = features n, columns = tokens m; whole rows of up to 256 tokens leave as 16-byte stores
+        float bn[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) bn[j] = e.bias ? e.bias[min(n0 + wc * 128 + 16 * j + l15, p.N - 1)] : 0.f;
+        const ImageOff io = w4_image_offsets(wc, wr, l15, l4);
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         static_for<0, 64>([&](auto tt) {
             constexpr int T = decltype(tt)::value, i = T >> 3, j = T & 7;
-            f32x4 v = acc_tile<T>();
-            const int nl = wc * 128 + 16 * j + l15;                 // image row
-            const int ml = wr * 128 + 16 * i + 4 * l4;              // image column (4 consecutive)
-            const float bn = e.bias ? e.bias[min(n0 + nl, p.N - 1)] : 0.f;
+            const f32x4 v = acc_tile<T>();
             u32x2 o;
-            o[0] = pack_bf16x2(v[0] + bn, v[1] + bn);
-            o[1] = pack_bf16x2(v[2] + bn, v[3] + bn);
-            *reinterpret_cast<u32x2*>(smem + nl * 512 + ((((ml >> 3) ^ nl) & 31) << 4) + ((ml >> 2) & 1) * 8) = o;
+            o[0] = pack_bf16x2(v[0] + bn[j], v[1] + bn[j]);
+            o[1] = pack_bf16x2(v[2] + bn[j], v[3] + bn[j]);
+            *reinterpret_cast<u32x2*>(smem + ((j & 1) ? io.o[i] : io.e[i]) + j * 8192) = o;
         });
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         w4_store_image(smem, e.outT + (int64_t)(n0 - e.n_split) * e.ldt, e.ldt, 0, min(256, p.N - n0), m0, min(256, p.M - m0));
@@ -295,17 +344,25 @@ __device__ __forceinline__ void w4_epilogue(const Problem& p, const Epilogue& e,
     } else {
         if (BF16_OUT && !p.epi_direct && (e.ldo % 8) == 0) {         // (workgroup-uniform)
             f32x4 b[8];
+            if (n0 + 256 <= p.N) {                                   // (workgroup-uniform)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int n = n0 + wc * 128 + 16 * j + 4 * l4;
-                b[j] = (e.bias && n + 3 < p.N) ? *reinterpret_cast<const f32x4*>(e.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+                for (int j = 0; j < 8; ++j)
+                    b[j] = e.bias ? *reinterpret_cast<const f32x4*>(e.bias + n0 + wc * 128 + 16 * j + 4 * l4) : f32x4{0.f, 0.f, 0.f, 0.f};
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int n = n0 + wc * 128 + 16 * j + 4 * l4;
+                    b[j] = (e.bias && n + 3 < p.N) ? *reinterpret_cast<const f32x4*>(e.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+                }
             }
+            const ImageOff io = w4_image_offsets(wr, wc, l15, l4);
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            TRACE_STAMP(3);
             static_for<0, 8>([&](auto ii) {
                 constexpr int i = decltype(ii)::value;
-                const int r = wr * 128 + 16 * i + l15;
                 u32x2 a2[8];
                 if constexpr (EPI == EPI_BF16_ADD) {              // the shortcut the conv output is added to: 8 loads in flight per row block
+                    const int r = wr * 128 + 16 * i + l15;
                     const int nl = n0 + wc * 128 + 4 * l4;
                     const unsigned short* ap = e.add + (int64_t)min(m0 + r, p.M - 1) * e.ldadd + nl;
 #pragma unroll
@@ -321,14 +378,14 @@ __device__ __forceinline__ void w4_epilogue(const Problem& p, const Epilogue& e,
                         v[2] += bf16_to_f32((unsigned short)(a2[j][1] & 0xffffu));
                         v[3] += bf16_to_f32((unsigned short)(a2[j][1] >> 16));
                     }
-                    const int cc = wc * 128 + 16 * j + 4 * l4;
                     u32x2 o;
                     o[0] = pack_bf16x2(v[0], v[1]);
                     o[1] = pack_bf16x2(v[2], v[3]);
-                    *reinterpret_cast<u32x2*>(smem + r * 512 + ((((cc >> 3) ^ r) & 31) << 4) + ((cc >> 2) & 1) * 8) = o;
+                    *reinterpret_cast<u32x2*>(smem + ((i & 1) ? io.o[j] : io.e[j]) + i * 8192) = o;
                 });
             });
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            TRACE_STAMP(4);
             if constexpr (EPI == EPI_BF16_TSPLIT) {
                 // out row m=(t,hw), col n=(j,c) -> out[((2t+j)*HW + hw), c]: a tile lies in one frame t and one channel half j (the caller checked
                 // HW % 256 == 0 and (N/2) % 256 == 0), so its rows stay consecutive
@@ -341,32 +398,44 @@ __device__ __forceinline__ void w4_epilogue(const Problem& p, const Epilogue& e,
         }
         const bool whole = m0 + 256 <= p.M && n0 + 256 <= p.N;       // (workgroup-uniform)
         if (EPI == YUME_EPI_RESID && whole) {
-            // fp32 residual stream, in place: x += (acc + bias) * gate. Per 16-row block i: the 8 x-loads (and gate loads) of the wave's 128
-            // columns are in flight together before the first use.
+            // fp32 residual stream, in place: x += (acc + bias) * gate. The loads of row block i + 2 (8 x vectors, 8 gate vectors of the wave's
+            // 128 columns) are issued behind the stores of block i: two blocks (32 KiB per wave) are in flight while one is combined.
             f32x4 b[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j)
                 b[j] = e.bias ? *reinterpret_cast<const f32x4*>(e.bias + n0 + wc * 128 + 16 * j + 4 * l4) : f32x4{0.f, 0.f, 0.f, 0.f};
-            static_for<0, 8>([&](auto ii) {
-                constexpr int i = decltype(ii)::value;
-                const int m = m0 + wr * 128 + 16 * i + l15;
-                float* xo = reinterpret_cast<float*>(e.out) + (int64_t)m * e.ldo + n0 + wc * 128 + 4 * l4;
-                f32x4 x[8], g[8];
+            const int mrow = m0 + wr * 128 + l15, ncol = n0 + wc * 128 + 4 * l4;
+            float* const xo = reinterpret_cast<float*>(e.out) + (int64_t)mrow * e.ldo + ncol;
+            const int64_t xstep = 16 * e.ldo;                          // floats between row blocks
+            const bool gated = e.gate != nullptr, rowed = gated && e.row_idx != nullptr;       // (workgroup-uniform)
+            int ridx[8];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) x[j] = *reinterpret_cast<const f32x4*>(xo + 16 * j);
-                if (e.gate) {
-                    const int64_t grow = e.row_idx ? (int64_t)e.row_idx[m] * e.gate_stride : 0;
-                    const float* gp = e.gate + grow + n0 + wc * 128 + 4 * l4;
+            for (int i = 0; i < 8; ++i) ridx[i] = rowed ? e.row_idx[mrow + 16 * i] : 0;
+            f32x4 x[2][8], g[2][8];
+            auto issue = [&](auto ii, auto bb) {
+                constexpr int i = decltype(ii)::value, bf = decltype(bb)::value;
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) g[j] = *reinterpret_cast<const f32x4*>(gp + 16 * j);
+                for (int j = 0; j < 8; ++j) x[bf][j] = *reinterpret_cast<const f32x4*>(xo + i * xstep + 16 * j);
+                if (rowed || (gated && i < 2)) {                       // one gate row for every token: loaded once per buffer
+                    const float* gp = e.gate + (int64_t)ridx[i] * e.gate_stride + ncol;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) g[bf][j] = *reinterpret_cast<const f32x4*>(gp + 16 * j);
                 }
+            };
+            issue(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+            issue(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{});
+            static_for<0, 8>([&](auto ii) {
+                constexpr int i = decltype(ii)::value, bf = i & 1;
                 static_for<0, 8>([&](auto jj) {
                     constexpr int j = decltype(jj)::value;
                     const f32x4 v = acc_tile<i * 8 + j>() + b[j];
-                    if (e.gate) x[j] += v * g[j];
-                    else x[j] += v;
-                    *reinterpret_cast<f32x4*>(xo + 16 * j) = x[j];
+                    if (gated) x[bf][j] += v * g[bf][j];
+                    else x[bf][j] += v;
+                    *reinterpret_cast<f32x4*>(xo + i * xstep + 16 * j) = x[bf][j];
                 });
+                if constexpr (i + 2 < 8) issue(std::integral_constant<int, i + 2>{}, std::integral_constant<int, bf>{});
+                if (i == 0) TRACE_STAMP(3);
+                if (i == 3) TRACE_STAMP(4);
             });
             return;
         }
@@ -458,6 +527,7 @@ template <int UNUSED = 0>      // (a template so that the header can be included
 __global__ __launch_bounds__(NTHR_W4, 1) void gemm_w4_kernel(Problem p, PlainA al, Epilogue e, int epi) {
     __shared__ __attribute__((aligned(16))) char smem[LDS_W4];
     int start, count, m0, n0;
+    TRACE_STAMP(0);
     xcd_chunk(p.tiles_m * p.tiles_n, blockIdx.x & 7, start, count);
     tile_origin(p, start + (blockIdx.x >> 3), m0, n0);
     if (epi == YUME_EPI_BF16_SPLITT && n0 >= e.n_split) {
@@ -466,6 +536,7 @@ __global__ __launch_bounds__(NTHR_W4, 1) void gemm_w4_kernel(Problem p, PlainA a
         return;
     }
     w4_mainloop<true>(p, al, smem, m0, n0);
+    TRACE_STAMP(1);
     switch (epi) {
 #ifndef W4_EXPERIMENT
         case YUME_EPI_BF16_GELU: w4_epilogue<YUME_EPI_BF16_GELU, true>(p, e, m0, n0, smem); break;
@@ -476,6 +547,7 @@ __global__ __launch_bounds__(NTHR_W4, 1) void gemm_w4_kernel(Problem p, PlainA a
 #endif
         default: w4_epilogue<YUME_EPI_BF16, true>(p, e, m0, n0, smem); break;
     }
+    TRACE_STAMP(2);
 }
 
 // shapes the kernel takes: at least two K tiles; 32-bit per-lane source offsets inside a tile's 256 rows
