@@ -352,6 +352,13 @@ __device__ __forceinline__ void fix7_v(const Dma7& d, const AttnArgs& p, int t, 
     }
 }
 
+// timing experiments (wrong results): the V^T fragment reads of block B's phases / the K cache refills left out
+#ifndef ATTN_ABLATE_VB
+#define ATTN_ABLATE_VB 0
+#endif
+#ifndef ATTN_ABLATE_KC
+#define ATTN_ABLATE_KC 0
+#endif
 // ---- a phase: 32 MFMA gaps ------------------------------------------------------------------------------------------------
 struct Ctx {
     char* smem;
@@ -413,8 +420,8 @@ __device__ __forceinline__ void phase(const Ctx& cx, Blk& X, Blk& Y, u32x4 (&rin
             if constexpr (((i) & 1) == 0) MFMA_O2(XO + 16 * (((i) - 16) & 3), ring[(i) & (RD - 1)], X.pf[((i) - 16) >> 2], ring[((i) + 1) & (RD - 1)], Y); \
             else MFMA_O(XO + 16 * (((i) - 16) & 3), ring[(i) & (RD - 1)], X.pf[((i) - 16) >> 2], Y);          \
         }                                                                                                    \
-        if constexpr (DO_PV && (i) + RD >= 16 && (i) + RD < 32) ring[(i) & (RD - 1)] = frag<(((i) + RD) & 15) + 16>(cx, vb); \
-        if constexpr (NKB >= 0 && (i) >= 1 && (i) <= 16)                                       \
+        if constexpr (DO_PV && (i) + RD >= 16 && (i) + RD < 32 && !(ATTN_ABLATE_VB && XO == OB)) ring[(i) & (RD - 1)] = frag<(((i) + RD) & 15) + 16>(cx, vb); \
+        if constexpr (NKB >= 0 && (i) >= 1 && (i) <= 16 && !ATTN_ABLATE_KC)                    \
             LOAD_KC(((i) - 1) & 15, cx.koff[(((i) - 1) & 15) >> 1], (NKB < 0 ? 0 : NKB) + ((((i) - 1) & 1) ? 32 * 256 : 0)); \
         if constexpr (DRAIN && (i) >= 1 && (i) < 5) PIN_BLK(X);     /* drain piece of the previous gap stays there */ \
         if constexpr (DRAIN && (i) < 4) sm_piece<32 + ((i) & 3), MASKX, FAST>(X.z, X.s, X.pf, cx.c, jx + cx.keyh, cx.Lk); \
