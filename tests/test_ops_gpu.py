@@ -100,13 +100,16 @@ def test_gemm_detects_transpose_and_permutation(variant):
     assert torch.equal(o.cpu(), w.to(torch.bfloat16).float().t().contiguous())
 
 
-@pytest.mark.parametrize("M,N,K,R", [(300, 512, 512, 2), (130, 3072, 1024, 1)])
+@pytest.mark.parametrize("M,N,K,R", [(300, 512, 512, 2), (130, 3072, 1024, 1), (1100, 512, 256, 3), (1100, 512, 256, -3)])
 @pytest.mark.parametrize("variant", [1, 2, 3])      # 128x128, 8-wave 256x256, one-wave-per-SIMD 256x256 (gemm_w4.hpp)
 def test_gemm_resid_gate(M, N, K, R, variant):
+    """R gate rows, interleaved over the tokens (R > 0) or in segments as the timesteps of a clip are (R < 0: whole waves share a row — the
+    one-wave-per-SIMD kernel then loads it once — except where a segment boundary crosses a tile)."""
+    segments, R = R < 0, abs(R)
     a, w, bias = rnd(M, K, seed=1, dtype=torch.bfloat16), rnd(N, K, seed=2, scale=K ** -0.5, dtype=torch.bfloat16), rnd(N, seed=3)
     x = rnd(M, N, seed=4)
     tab = rnd(R, 6, N, seed=5)
-    idx = (torch.arange(M) % R).to(torch.int32)
+    idx = ((torch.arange(M) * R // M) if segments else (torch.arange(M) % R)).to(torch.int32)
     xd = x.to(DEV).clone()
     tabd = tab.to(DEV)
     ops.gemm_bf16(a.to(DEV), w.to(DEV), bias.to(DEV), xd, ops.EPI_RESID, gate=tabd[:, 2], gate_stride=6 * N,

@@ -41,7 +41,9 @@ static int run_case(const Case& c, const std::vector<int>& variants, int reps, b
     for (auto& x : gate) x = rnd();
     for (auto& x : x0) x = rnd();
     std::vector<int32_t> ridx(M);
-    for (int64_t m = 0; m < M; ++m) ridx[m] = c.R > 1 ? (int32_t)((m * 7) % c.R) : 0;
+    // gate rows: interleaved for the small cases (every wave sees several), in segments as the tokens' timesteps are for the big ones (a wave's
+    // 128 rows share one row except across the segment boundaries, which fall inside tiles)
+    for (int64_t m = 0; m < M; ++m) ridx[m] = c.R > 1 ? (M >= 2048 ? (int32_t)(m * c.R / M) : (int32_t)((m * 7) % c.R)) : 0;
     const int64_t nsplit = c.epi == YUME_EPI_BF16_SPLITT ? (N / 3 / 128) * 128 * 2 : 0;      // q|k row-major, v transposed
     const int64_t ldt = (M + 7) / 8 * 8;
     void *da, *dw, *dout, *dt = nullptr; float *dbias, *dgate; int32_t* dr;

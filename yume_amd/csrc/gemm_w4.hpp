@@ -407,23 +407,39 @@ __device__ __forceinline__ void w4_epilogue(const Problem& p, const Epilogue& e,
             const int mrow = m0 + wr * 128 + l15, ncol = n0 + wc * 128 + 4 * l4;
             float* const xo = reinterpret_cast<float*>(e.out) + (int64_t)mrow * e.ldo + ncol;
             const int64_t xstep = 16 * e.ldo;                          // floats between row blocks
-            const bool gated = e.gate != nullptr, rowed = gated && e.row_idx != nullptr;       // (workgroup-uniform)
+            const bool gated = e.gate != nullptr;                      // (workgroup-uniform)
+            bool rowed = gated && e.row_idx != nullptr;                // (wave-uniform)
             int ridx[8];
 #pragma unroll
             for (int i = 0; i < 8; ++i) ridx[i] = rowed ? e.row_idx[mrow + 16 * i] : 0;
             f32x4 x[2][8], g[2][8];
-            auto issue = [&](auto ii, auto bb) {
+            auto issue_x = [&](auto ii, auto bb) {
                 constexpr int i = decltype(ii)::value, bf = decltype(bb)::value;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) x[bf][j] = *reinterpret_cast<const f32x4*>(xo + i * xstep + 16 * j);
+            };
+            auto issue_g = [&](auto ii, auto bb) {
+                constexpr int i = decltype(ii)::value, bf = decltype(bb)::value;
                 if (rowed || (gated && i < 2)) {                       // one gate row for every token: loaded once per buffer
                     const float* gp = e.gate + (int64_t)ridx[i] * e.gate_stride + ncol;
 #pragma unroll
                     for (int j = 0; j < 8; ++j) g[bf][j] = *reinterpret_cast<const f32x4*>(gp + 16 * j);
                 }
             };
-            issue(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
-            issue(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{});
+            // the x loads of the first two row blocks go out before anything waits for the row indices
+            issue_x(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+            issue_x(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{});
+            if (rowed) {
+                // the gate rows follow the tokens' timestep segments: the 128 rows of a wave almost always share one, and then its 8 vectors
+                // are loaded once (as for an un-indexed gate) instead of once per row block — half of the epilogue's load instructions
+                const int r0 = __builtin_amdgcn_readfirstlane(ridx[0]);
+                bool same = true;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) same &= ridx[i] == r0;
+                if (__all(same)) rowed = false;
+            }
+            issue_g(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+            issue_g(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{});
             static_for<0, 8>([&](auto ii) {
                 constexpr int i = decltype(ii)::value, bf = i & 1;
                 static_for<0, 8>([&](auto jj) {
@@ -433,7 +449,10 @@ __device__ __forceinline__ void w4_epilogue(const Problem& p, const Epilogue& e,
                     else x[bf][j] += v;
                     *reinterpret_cast<f32x4*>(xo + i * xstep + 16 * j) = x[bf][j];
                 });
-                if constexpr (i + 2 < 8) issue(std::integral_constant<int, i + 2>{}, std::integral_constant<int, bf>{});
+                if constexpr (i + 2 < 8) {
+                    issue_x(std::integral_constant<int, i + 2>{}, std::integral_constant<int, bf>{});
+                    issue_g(std::integral_constant<int, i + 2>{}, std::integral_constant<int, bf>{});
+                }
                 if (i == 0) TRACE_STAMP(3);
                 if (i == 3) TRACE_STAMP(4);
             });
