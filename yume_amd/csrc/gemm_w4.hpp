@@ -396,8 +396,9 @@ __device__ __forceinline__ void w4_epilogue(const Problem& p, const Epilogue& e,
             }
             return;
         }
-        const bool whole = m0 + 256 <= p.M && n0 + 256 <= p.N;       // (workgroup-uniform)
-        if (EPI == YUME_EPI_RESID && whole) {
+        // whole columns (workgroup-uniform); rows beyond M — the last row of tiles of a ragged M — read row M - 1 and store nothing (that tile
+        // is among the last to finish: on the generic guarded path below its epilogue took 64 - 76 us instead of 20 and set the end of the launch)
+        if (EPI == YUME_EPI_RESID && n0 + 256 <= p.N) {
             // fp32 residual stream, in place: x += (acc + bias) * gate. The loads of row block i + 2 (8 x vectors, 8 gate vectors of the wave's
             // 128 columns) are issued behind the stores of block i: two blocks (32 KiB per wave) are in flight while one is combined.
             f32x4 b[8];
@@ -405,18 +406,22 @@ __device__ __forceinline__ void w4_epilogue(const Problem& p, const Epilogue& e,
             for (int j = 0; j < 8; ++j)
                 b[j] = e.bias ? *reinterpret_cast<const f32x4*>(e.bias + n0 + wc * 128 + 16 * j + 4 * l4) : f32x4{0.f, 0.f, 0.f, 0.f};
             const int mrow = m0 + wr * 128 + l15, ncol = n0 + wc * 128 + 4 * l4;
+            const bool ragged_m = m0 + 256 > p.M;                      // (workgroup-uniform)
+            const int mlast = p.M - 1 - mrow;                          // row block i is inside the matrix iff 16 i <= mlast
             float* const xo = reinterpret_cast<float*>(e.out) + (int64_t)mrow * e.ldo + ncol;
             const int64_t xstep = 16 * e.ldo;                          // floats between row blocks
+            // row block i of this lane: its offset from xo in floats (clamped to the matrix's last row in a ragged tile)
+            auto xoff = [&](int i) -> int64_t { return ragged_m ? (int64_t)(min(16 * i, mlast) ) * e.ldo : i * xstep; };
             const bool gated = e.gate != nullptr;                      // (workgroup-uniform)
             bool rowed = gated && e.row_idx != nullptr;                // (wave-uniform)
             int ridx[8];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) ridx[i] = rowed ? e.row_idx[mrow + 16 * i] : 0;
+            for (int i = 0; i < 8; ++i) ridx[i] = rowed ? e.row_idx[min(mrow + 16 * i, p.M - 1)] : 0;
             f32x4 x[2][8], g[2][8];
             auto issue_x = [&](auto ii, auto bb) {
                 constexpr int i = decltype(ii)::value, bf = decltype(bb)::value;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) x[bf][j] = *reinterpret_cast<const f32x4*>(xo + i * xstep + 16 * j);
+                for (int j = 0; j < 8; ++j) x[bf][j] = *reinterpret_cast<const f32x4*>(xo + xoff(i) + 16 * j);
             };
             auto issue_g = [&](auto ii, auto bb) {
                 constexpr int i = decltype(ii)::value, bf = decltype(bb)::value;
@@ -447,7 +452,7 @@ __device__ __forceinline__ void w4_epilogue(const Problem& p, const Epilogue& e,
                     const f32x4 v = acc_tile<i * 8 + j>() + b[j];
                     if (gated) x[bf][j] += v * g[bf][j];
                     else x[bf][j] += v;
-                    *reinterpret_cast<f32x4*>(xo + i * xstep + 16 * j) = x[bf][j];
+                    if (!ragged_m || 16 * i <= mlast) *reinterpret_cast<f32x4*>(xo + i * xstep + 16 * j) = x[bf][j];
                 });
                 if constexpr (i + 2 < 8) {
                     issue_x(std::integral_constant<int, i + 2>{}, std::integral_constant<int, bf>{});
