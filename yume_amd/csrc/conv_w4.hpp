@@ -24,6 +24,13 @@ struct ConvW4 {
     int Tin, Hin, Win, Cin, To, Ho, Wo;
     int kt, kh, kw, pt, ph, pw;
     int ups;                       // the conv reads the nearest-2x upsampled view of x (Ho = 2 Hin, Wo = 2 Win)
+    // Long launches (>= 8 rounds of tiles): the XCDs of one chip do not run the same code equally fast (the starts of a round drift apart
+    // by about a tile time per 12 rounds, profiles/r3_gemm_w4.md section 7), and a static split leaves the fast ones idle at the end. The
+    // last `dyn` tiles of every XCD's chunk are handed out by ticket (steal[xcd], zeroed before the launch): first to the XCD's own
+    // workgroups, then to workgroups of XCDs whose own tickets have run out — among them 32 surplus workgroups per XCD that exist only
+    // to steal. nullptr: the static split.
+    int* steal;
+    int dyn;
 };
 
 // wave-uniform walk of the K tiles (the tile to STAGE): order (dt, channel tile, dh, dw)
@@ -191,16 +198,41 @@ template <int UNUSED = 0>
 __global__ __launch_bounds__(NTHR_W4, 1) void conv_w4_kernel(Problem p, ConvW4 cv, Epilogue e, int epi) {
     __shared__ __attribute__((aligned(16))) char smem[LDS_W4];
     int start, count, m0, n0;
-    xcd_chunk(p.tiles_m * p.tiles_n, blockIdx.x & 7, start, count);
-    tile_origin(p, start + (blockIdx.x >> 3), m0, n0);
+    TRACE_STAMP(0);
+    const int ntile = p.tiles_m * p.tiles_n, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    xcd_chunk(ntile, xcd, start, count);
+    int tile = start + idx;
+    if (cv.steal != nullptr && idx >= count - cv.dyn) {            // (workgroup-uniform) one of the ticketed tiles, or a surplus workgroup
+        int* slot = reinterpret_cast<int*>(smem);
+        if (threadIdx.x == 0) {
+            int got = -1;
+            const int dx = min(count, cv.dyn), t = atomicAdd(&cv.steal[xcd], 1);
+            if (t < dx) got = start + count - dx + t;
+            for (int k = 1; k < 8 && got < 0; ++k) {
+                const int y = (xcd + k) & 7;
+                int sy, cy;
+                xcd_chunk(ntile, y, sy, cy);
+                const int dy = min(cy, cv.dyn), ty = atomicAdd(&cv.steal[y], 1);
+                if (ty < dy) got = sy + cy - dy + ty;
+            }
+            *slot = got;
+        }
+        __syncthreads();
+        tile = *slot;
+        __syncthreads();                                           // (the K loop's first LDS-DMA piece lands on the slot)
+        if (tile < 0) return;
+    }
+    tile_origin(p, tile, m0, n0);
     if (cv.ups) conv_w4_mainloop<2>(p, cv, smem, m0, n0);
     else conv_w4_mainloop<1>(p, cv, smem, m0, n0);
+    TRACE_STAMP(1);
     switch (epi) {
         case YUME_EPI_F32: w4_epilogue<YUME_EPI_F32, true>(p, e, m0, n0, smem); break;
         case EPI_BF16_ADD: w4_epilogue<EPI_BF16_ADD, true>(p, e, m0, n0, smem); break;
         case EPI_BF16_TSPLIT: w4_epilogue<EPI_BF16_TSPLIT, true>(p, e, m0, n0, smem); break;
         default: w4_epilogue<YUME_EPI_BF16, true>(p, e, m0, n0, smem); break;
     }
+    TRACE_STAMP(2);
 }
 
 // what the kernel takes (host): stride 1, no folded upsample, Cin in whole K tiles, frames in whole M tiles, >= 3 K tiles, 32-bit offsets
@@ -222,7 +254,34 @@ inline int launch_conv_w4(int epi, const Problem& p128, const ConvW4& cv, const 
     p.tiles_n = (p.N + 255) / 256;
     p.group_m = g_group_m;
     p.epi_direct = 0;
-    hipLaunchKernelGGL(conv_w4_kernel<0>, dim3((unsigned)(p.tiles_m * p.tiles_n)), dim3(NTHR_W4), 0, st, p, cv, e, epi);
+    const int ntile = p.tiles_m * p.tiles_n;
+    ConvW4 c = cv;
+    c.steal = nullptr;
+    c.dyn = 0;
+    unsigned grid = (unsigned)ntile;
+    static const bool steal_on = [] { const char* v = getenv("YUME_CONV_STEAL"); return !v || atoi(v) != 0; }();
+    if (steal_on && ntile >= 8 * 256) {
+        // ticket counters: a ring of 64 sets per device (a set is in use for one launch; 64 convolutions of one process in flight at once
+        // on one device would be needed for two launches to meet on a set)
+        constexpr int SETS = 64, MAXDEV = 16;
+        static int* ring[MAXDEV] = {};
+        static unsigned next[MAXDEV] = {};
+        int dev = 0;
+        if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < MAXDEV) {
+            if (!ring[dev] && hipMalloc(&ring[dev], SETS * 8 * sizeof(int)) != hipSuccess) ring[dev] = nullptr;
+            if (ring[dev]) {
+                c.steal = ring[dev] + 8 * (next[dev]++ % SETS);
+                c.dyn = 96;
+                if (hipMemsetAsync(c.steal, 0, 8 * sizeof(int), st) != hipSuccess) {
+                    c.steal = nullptr;
+                    c.dyn = 0;
+                } else {
+                    grid += 8 * 32;
+                }
+            }
+        }
+    }
+    hipLaunchKernelGGL(conv_w4_kernel<0>, dim3(grid), dim3(NTHR_W4), 0, st, p, c, e, epi);
     YUME_CHECK_LAUNCH(what);
     return YUME_OK;
 }
