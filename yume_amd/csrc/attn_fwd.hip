@@ -22,6 +22,7 @@
 // Roofline: MFMA (bf16 dense). Algorithmic work 4*Lq*Lk*128 flop per head.
 #include "common.hpp"
 #include "attn_args.hpp"
+#include "trace.hpp"
 
 namespace {
 
@@ -456,6 +457,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel_v2(AttnArgs p) {
         h = xcd + 8 * (idx / p.nqb);
         qb = idx % p.nqb;
     }
+    TRACE_STAMP(0);
     const int q0 = p.q_lo + qb * QB + wave * QW;
     bf16x8_t qf[8];
     {
@@ -501,6 +503,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel_v2(AttnArgs p) {
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    TRACE_STAMP(3);
 
     int cur = 0;
     for (int t = t0; t < t1; ++t) {
@@ -544,6 +547,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel_v2(AttnArgs p) {
         return;
     }
 
+    TRACE_STAMP(1);
     const float l_tot = xhalf_sum(l_run);
     const float inv = 1.0f / l_tot;
     const int q = q0 + ql;
@@ -569,6 +573,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel_v2(AttnArgs p) {
                 *dst = o;
             }
     }
+    TRACE_STAMP(2);
 }
 
 
