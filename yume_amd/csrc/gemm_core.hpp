@@ -22,6 +22,7 @@
 // resident on one XCD share A row-panels and W column-panels in that XCD's L2.
 #pragma once
 #include "common.hpp"
+#include "trace.hpp"
 #include <stdlib.h>
 #include <type_traits>
 
@@ -253,6 +254,7 @@ __global__ __launch_bounds__(NTHR, 2) void gemm128_kernel(Problem p, ALoad al, E
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    TRACE_STAMP(0);
     const int nk = p.K / BK;
     al.init(m0, tid);
     stage_a(al, 0, smem, wave);
@@ -288,6 +290,7 @@ __global__ __launch_bounds__(NTHR, 2) void gemm128_kernel(Problem p, ALoad al, E
         cur ^= 1;
     }
     __syncthreads();  // all waves finished with the operand tiles; LDS is reused for the epilogue
+    TRACE_STAMP(1);
 
     // ---- epilogue: per-wave 64x64 fp32 restage (16 KiB per wave) ----
     float* ep = reinterpret_cast<float*>(smem) + wave * (64 * 64);
@@ -298,6 +301,7 @@ __global__ __launch_bounds__(NTHR, 2) void gemm128_kernel(Problem p, ALoad al, E
 #pragma unroll
         for (int j = 0; j < 4; ++j) stage_acc(ep, acc[i][j], i, j, lane, transposed);
     wave_epilogue<EPI>(ep, transposed, p, e, lane, wm0, wn0, wn0 + 32);
+    TRACE_STAMP(2);
 }
 
 // =====================================================================================================================
