@@ -14,6 +14,8 @@
 // Everything else — LDS images, fragment reads, gap plan, epilogues — is gemm_w4.hpp's.
 #pragma once
 #include "gemm_w4.hpp"
+#include <atomic>
+#include <mutex>
 
 namespace gemm_w4 {
 
@@ -265,12 +267,18 @@ inline int launch_conv_w4(int epi, const Problem& p128, const ConvW4& cv, const 
         // on one device would be needed for two launches to meet on a set)
         constexpr int SETS = 64, MAXDEV = 16;
         static int* ring[MAXDEV] = {};
-        static unsigned next[MAXDEV] = {};
+        static std::atomic<unsigned> next[MAXDEV];
+        static std::mutex ring_mutex;                      // (host threads may launch convolutions concurrently)
         int dev = 0;
         if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < MAXDEV) {
-            if (!ring[dev] && hipMalloc(&ring[dev], SETS * 8 * sizeof(int)) != hipSuccess) ring[dev] = nullptr;
-            if (ring[dev]) {
-                c.steal = ring[dev] + 8 * (next[dev]++ % SETS);
+            int* mine;
+            {
+                std::lock_guard<std::mutex> lock(ring_mutex);
+                if (!ring[dev] && hipMalloc(&ring[dev], SETS * 8 * sizeof(int)) != hipSuccess) ring[dev] = nullptr;
+                mine = ring[dev];
+            }
+            if (mine) {
+                c.steal = mine + 8 * (next[dev].fetch_add(1u) % SETS);
                 c.dyn = 96;
                 if (hipMemsetAsync(c.steal, 0, 8 * sizeof(int), st) != hipSuccess) {
                     c.steal = nullptr;
