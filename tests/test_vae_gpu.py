@@ -283,6 +283,26 @@ def test_conv_w4_3x3x3_and_skip_vs_torch(Cin, Cout, T, H, W, with_cache):
     assert rel_l2(ncthw(out), want + skip) < 5e-3
 
 
+def test_conv_w4_long_launch_ticketed_tail_vs_torch():
+    """>= 8 rounds of tiles (2112 here): the last tiles of every XCD's chunk go out by ticket and surplus workgroups steal across XCDs
+    (conv_w4.hpp) — every tile still computed exactly once, whoever computes it."""
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    Cin, Cout, T, H, W = 64, 256, 3, 352, 512
+    assert T * H * W // 256 >= 8 * 256
+    x = rnd(Cin, T, H, W, seed=31).bfloat16().float()
+    cache = rnd(Cin, 2, H, W, seed=32).bfloat16().float()
+    w = (rnd(Cout, Cin, 3, 3, 3, seed=33) * (27 * Cin) ** -0.5).bfloat16().float()
+    b = rnd(Cout, seed=34) * 0.1
+    want = F.conv3d(F.pad(torch.cat([cache, x], dim=1).unsqueeze(0), (1, 1, 1, 1)), w, b)[0]
+    out = torch.full((T, H, W, Cout), float("nan"), dtype=torch.bfloat16, device=DEV)
+    for _ in range(2):                                   # (the second launch takes the next counter set of the ring)
+        V.conv3d_cl(cl(x), cl(cache), pack_w(w), b.to(DEV), Cout, (3, 3, 3), (1, 1, 1), (2, 1, 1), False, out, V.EPI_BF16, zero_page=zero_page())
+    got = ncthw(out)
+    assert torch.isfinite(got).all()                     # no tile left out
+    assert (got - want).abs().max() <= 2.0 ** -7 * want.abs().max() + 1e-3
+    assert rel_l2(got, want) < 5e-3
+
+
 def test_conv_w4_folded_upsample_and_time_conv_vs_torch():
     torch.set_num_threads(min(32, torch.get_num_threads()))
     C, Co, T, H, W = 64, 128, 2, 80, 80                              # 160 x 160 output frames = 100 tiles each
