@@ -8,7 +8,8 @@ import os
 from ctypes import c_void_p, c_int, c_int64, c_float, c_char_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libyume_hip.so")
+# YUME_HIP_LIB: an experiment build of the same ABI (tools/build_variant.sh) instead of the product library — A/B runs of whole benches
+LIB_PATH = os.environ.get("YUME_HIP_LIB") or os.path.join(_HERE, "lib", "libyume_hip.so")
 
 _P, _I, _L, _F = c_void_p, c_int, c_int64, c_float
 
