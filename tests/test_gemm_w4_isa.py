@@ -80,3 +80,37 @@ def test_w4_kernels_own_their_accumulators_and_follow_the_gap_plan(src, kernel, 
         assert len(vm) == 1 and "lgkmcnt" not in vm[0], vm          # the one counted wait of the plan; hipcc adds none (it would drain the DMA in flight)
         assert not [x for x in blk if x.startswith("v_accvgpr")] and sum(x.startswith("v_mov_b32") for x in blk) <= 4, "register shuffling inside the steady loop"
         assert len(blk) <= budget * 128, f"{len(blk)} instructions for 128 MFMAs"
+
+
+def test_w4_bf16_epilogue_stays_lean():
+    """What the per-workgroup trace of r3 paid for (profiles/r3_gemm_w4.md section 7): the accumulator -> LDS image pass of a bf16 tile is
+    ~10 instructions per 16x16 accumulator tile (4 v_accvgpr_read, 2 packed adds, 2 packed converts, 1 ds_write_b64 with the row-block offset
+    in its offset field) — no per-tile address arithmetic — and the image -> global pass keeps 8 image reads in flight ahead of their stores
+    instead of read / wait / 64-bit multiply / store per row."""
+    body, _ = _kernel_body(_asm("gemm_bf16.hip"), "_ZN7gemm_w414gemm_w4_kernelILi0EE")
+    ins = [x.strip() for x in body if x.strip() and x.strip()[0] not in ";." and not x.strip().endswith(":")]
+    w = [i for i, x in enumerate(ins) if x.startswith("ds_write_b64")]
+    runs, cur = [], [w[0]]
+    for i in w[1:]:
+        if i - cur[-1] > 60:
+            runs.append(cur)
+            cur = [i]
+        else:
+            cur.append(i)
+    runs.append(cur)
+    images = [r for r in runs if len(r) == 64]                       # one per bf16-output epilogue (plain, GELU, erf-GELU, q|k of SPLITT, V^T)
+    assert len(images) >= 4
+    plain = [r for r in images if not any(op.startswith(("v_exp_f32", "v_rcp_f32", "v_fma")) for op in ins[r[0]:r[-1]])]
+    assert plain, "no plain bf16 image pass found"
+    for r in plain:
+        span = ins[r[0] - 8:r[-1] + 1]
+        assert len(span) <= 64 * 12.5, f"{len(span)} instructions for 64 accumulator tiles"
+        assert not [x for x in span if x.startswith(("v_mul_lo", "v_mad_u64", "v_lshl_add_u64"))], "per-tile address arithmetic is back"
+    # image -> global: somewhere 8 ds_read_b128 stand in a row (no store between them), followed by global_store_dwordx4
+    mem = [x.split()[0] for x in ins if x.startswith(("ds_read_b128", "global_store_dwordx4", "s_barrier", "v_mfma"))]
+    best, run = 0, 0
+    for i, op in enumerate(mem):
+        run = run + 1 if op == "ds_read_b128" else 0
+        if run >= 8 and i + 1 < len(mem) and mem[i + 1] == "global_store_dwordx4":
+            best = max(best, run)
+    assert best >= 8, "the image -> global pass no longer batches its reads"
