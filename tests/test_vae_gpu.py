@@ -331,6 +331,44 @@ def test_conv_w4_folded_upsample_and_time_conv_vs_torch():
     assert rel_l2(ncthw(out), want) < 5e-3
 
 
+def test_conv_w4_frames_that_are_not_whole_tiles_vs_torch():
+    """The decoder's 44 x 80 level: 3520 positions per frame = 13 tiles + 192 rows. A frame takes 14 tiles; the last one's rows beyond the
+    frame read nothing and are not stored (conv_w4.hpp). 3x3x3 with the cache, the fused skip, and the frame-interleaving time_conv."""
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    Cin, Cout, T, H, W = 128, 1024, 4, 44, 80
+    x = rnd(Cin, T, H, W, seed=41).bfloat16().float()
+    cache = rnd(Cin, 2, H, W, seed=42).bfloat16().float()
+    w = (rnd(Cout, Cin, 3, 3, 3, seed=43) * (27 * Cin) ** -0.5).bfloat16().float()
+    b = rnd(Cout, seed=44) * 0.1
+    want = F.conv3d(F.pad(torch.cat([cache, x], dim=1).unsqueeze(0), (1, 1, 1, 1)), w, b)[0]
+    out = torch.full((T + 1, H, W, Cout), 7.0, dtype=torch.bfloat16, device=DEV)          # one guard frame behind the output
+    V.conv3d_cl(cl(x), cl(cache), pack_w(w), b.to(DEV), Cout, (3, 3, 3), (1, 1, 1), (2, 1, 1), False, out[:T], V.EPI_BF16, zero_page=zero_page())
+    got = ncthw(out[:T])
+    assert (out[T] == 7.0).all()                                     # nothing written beyond the last frame
+    assert (got - want).abs().max() <= 2.0 ** -7 * want.abs().max() + 1e-3
+    assert rel_l2(got, want) < 5e-3
+    for t in range(T):                                               # the last rows of every frame (its ragged tile) separately
+        assert rel_l2(got[:, t, -4:], want[:, t, -4:]) < 5e-3
+    skip = rnd(Cout, T, H, W, seed=45).bfloat16().float()
+    V.conv3d_cl(cl(x), cl(cache), pack_w(w), b.to(DEV), Cout, (3, 3, 3), (1, 1, 1), (2, 1, 1), False, out[:T], V.EPI_ADD, add=cl(skip),
+                zero_page=zero_page())
+    assert rel_l2(ncthw(out[:T]), want + skip) < 5e-3
+    assert (out[T] == 7.0).all()
+    # time_conv at this level: C -> 2C, frames interleaved
+    C = 512
+    x = rnd(C, T, H, W, seed=46).bfloat16().float()
+    cache = rnd(C, 2, H, W, seed=47).bfloat16().float()
+    w = (rnd(2 * C, C, 3, 1, 1, seed=48) * (3 * C) ** -0.5).bfloat16().float()
+    b = rnd(2 * C, seed=49) * 0.1
+    y = F.conv3d(torch.cat([cache, x], 1).unsqueeze(0), w, b)[0].reshape(2, C, T, H, W)
+    want = torch.stack((y[0], y[1]), dim=2).reshape(C, 2 * T, H, W)
+    out = torch.full((2 * T + 1, H, W, C), 7.0, dtype=torch.bfloat16, device=DEV)
+    V.conv3d_cl(cl(x), cl(cache), pack_w(w), b.to(DEV), 2 * C, (3, 1, 1), (1, 1, 1), (2, 0, 0), False, out[:2 * T], V.EPI_TSPLIT,
+                zero_page=zero_page())
+    assert rel_l2(ncthw(out[:2 * T]), want) < 5e-3
+    assert (out[2 * T] == 7.0).all()
+
+
 @pytest.mark.parametrize("with_cache", [False, True])
 def test_conv_halo_head_vs_torch(with_cache):
     """256 x 256 frames, 64 / 128 input channels, 12 output channels in a 16-channel row: conv_halo16_kernel (ragged right / bottom tiles too)."""

@@ -120,8 +120,10 @@ __device__ __forceinline__ void conv_w4_loop(Ctx& c, const ConvW4& cv, ConvWalk&
     }
 }
 
+// to: output frame of the tile, r0: its first position inside the frame (a tile never spans two frames: a frame of Ho*Wo positions takes
+// ceil(Ho*Wo / 256) tiles, the rows of its last tile beyond the frame read nothing — every tap masked — and are not stored)
 template <int CONV>
-__device__ __forceinline__ void conv_w4_mainloop(const Problem& p, const ConvW4& cv, char* smem, int m0, int n0) {
+__device__ __forceinline__ void conv_w4_mainloop(const Problem& p, const ConvW4& cv, char* smem, int to, int r0, int n0) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -134,12 +136,10 @@ __device__ __forceinline__ void conv_w4_mainloop(const Problem& p, const ConvW4&
     const char* pbw = reinterpret_cast<const char*>(p.W + (int64_t)n0 * p.ldw);
     const unsigned ldc2 = (unsigned)cv.ldc * 2u, ldw_b = (unsigned)p.ldw * 2u;
     const int HW = cv.Ho * cv.Wo;
-    const int to = m0 / HW;                       // (a tile lies inside one output frame: HW % 256 == 0)
     {
         const int rl = 8 * wave + (lane >> 3);
         const unsigned ch = (unsigned)(((lane & 7) ^ (rl & 7)) << 4);
         const int nleft = p.N - 1 - n0;
-        const int r0 = m0 - to * HW;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int r = 32 * j + rl;
@@ -160,7 +160,7 @@ __device__ __forceinline__ void conv_w4_mainloop(const Problem& p, const ConvW4&
                     for (int b = 0; b < cv.kw; ++b)
                         if (hh + a >= 0 && hh + a < cv.Hin && ww + b >= 0 && ww + b < cv.Win) mk |= 1u << (a * cv.kw + b);
             }
-            c.mask[j] = mk;
+            c.mask[j] = pos < HW ? mk : 0u;
             c.vb[j] = (unsigned)min(r, nleft) * ldw_b + ch;
         }
     }
@@ -224,25 +224,36 @@ __global__ __launch_bounds__(NTHR_W4, 1) void conv_w4_kernel(Problem p, ConvW4 c
         __syncthreads();                                           // (the K loop's first LDS-DMA piece lands on the slot)
         if (tile < 0) return;
     }
-    tile_origin(p, tile, m0, n0);
-    if (cv.ups) conv_w4_mainloop<2>(p, cv, smem, m0, n0);
-    else conv_w4_mainloop<1>(p, cv, smem, m0, n0);
+    tile_origin(p, tile, m0, n0);                 // m0 = 256 x (row of tiles); p.tiles_m = To x tiles per frame
+    const int HW = cv.Ho * cv.Wo, tpf = (HW + 255) >> 8, tm = m0 >> 8;
+    const int to = tm / tpf, r0 = (tm - to * tpf) << 8;
+    if (cv.ups) conv_w4_mainloop<2>(p, cv, smem, to, r0, n0);
+    else conv_w4_mainloop<1>(p, cv, smem, to, r0, n0);
     TRACE_STAMP(1);
+    // the epilogue sees the tile's frame as the end of the matrix: output rows [to*HW + r0, (to+1)*HW) — whole tiles when HW % 256 == 0
+    Problem pe = p;
+    pe.M = (to + 1) * HW;
+    m0 = to * HW + r0;
     switch (epi) {
-        case YUME_EPI_F32: w4_epilogue<YUME_EPI_F32, true>(p, e, m0, n0, smem); break;
-        case EPI_BF16_ADD: w4_epilogue<EPI_BF16_ADD, true>(p, e, m0, n0, smem); break;
-        case EPI_BF16_TSPLIT: w4_epilogue<EPI_BF16_TSPLIT, true>(p, e, m0, n0, smem); break;
-        default: w4_epilogue<YUME_EPI_BF16, true>(p, e, m0, n0, smem); break;
+        case YUME_EPI_F32: w4_epilogue<YUME_EPI_F32, true>(pe, e, m0, n0, smem); break;
+        case EPI_BF16_ADD: w4_epilogue<EPI_BF16_ADD, true>(pe, e, m0, n0, smem); break;
+        case EPI_BF16_TSPLIT: w4_epilogue<EPI_BF16_TSPLIT, true>(pe, e, m0, n0, smem); break;
+        default: w4_epilogue<YUME_EPI_BF16, true>(pe, e, m0, n0, smem); break;
     }
     TRACE_STAMP(2);
 }
 
-// what the kernel takes (host): stride 1, no folded upsample, Cin in whole K tiles, frames in whole M tiles, >= 3 K tiles, 32-bit offsets
+// what the kernel takes (host): stride 1, Cin in whole K tiles, frames of at least 1024 positions (a frame takes ceil(Ho*Wo / 256) tiles:
+// at most 20 % of the rows of its tiles idle; the decoder's 44 x 80 level: 1.8 %), >= 3 K tiles, 32-bit offsets
 inline bool conv_w4_applies(const Problem& p, const ConvW4& cv, int st, int sh, int sw, int ups, int epi) {
     static const bool on = [] { const char* v = getenv("YUME_CONV_W4"); return !v || atoi(v) != 0; }();
     if (!on || st != 1 || sh != 1 || sw != 1) return false;
     if (ups && (cv.kt != 1 || cv.kh != 3 || cv.kw != 3 || cv.ph != 1 || cv.pw != 1 || cv.pt != 0 || cv.Ho != 2 * cv.Hin || cv.Wo != 2 * cv.Win)) return false;
-    if ((cv.Cin % BK) != 0 || ((int64_t)cv.Ho * cv.Wo) % 256 != 0 || cv.kh * cv.kw > 32 || p.K < 3 * BK) return false;
+    // (the folded-upsample source keeps whole-tile frames: at few frames per pass its launches fall to the gathering kernel, which sums the
+    // taps in the weight's own order — a ragged level on this kernel only when many frames are batched would make the one-latent-per-pass
+    // walk and the grouped pass of the decoder differ in their last bits, tests/test_live_fullsize_gpu.py)
+    if (ups && ((int64_t)cv.Ho * cv.Wo) % 256 != 0) return false;
+    if ((cv.Cin % BK) != 0 || (int64_t)cv.Ho * cv.Wo < 1024 || (int64_t)cv.Ho * cv.Wo * cv.To >= (1ll << 31) || cv.kh * cv.kw > 32 || p.K < 3 * BK) return false;
     if ((int64_t)cv.Hin * cv.Win * cv.ldc * 2 + (int64_t)(cv.kh * cv.Win + cv.kw) * cv.ldc * 2 >= 0x7fffff00ll) return false;
     if (255ll * p.ldw * 2 + 128 >= (1ll << 32)) return false;
     if (cv.pt > 2 || (int64_t)p.tiles_m * p.tiles_n * 4 < 192) return false;          // too few tiles to fill the chip: the 128x128 kernel's job
@@ -252,7 +263,7 @@ inline bool conv_w4_applies(const Problem& p, const ConvW4& cv, int st, int sh, 
 
 inline int launch_conv_w4(int epi, const Problem& p128, const ConvW4& cv, const Epilogue& e, hipStream_t st, const char* what) {
     Problem p = p128;
-    p.tiles_m = (p.M + 255) / 256;
+    p.tiles_m = cv.To * ((cv.Ho * cv.Wo + 255) / 256);          // whole frames of tiles
     p.tiles_n = (p.N + 255) / 256;
     p.group_m = g_group_m;
     p.epi_direct = 0;
