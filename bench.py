@@ -132,7 +132,7 @@ def vae_cpu_baseline():
     assert torch.isfinite(out).all()
     tf = fc.get_total_flops() / 1e12
     torch.set_num_threads(os.cpu_count() or 1)
-    return {"value": (tf / dt) / (485.04 / 8.0), "unit": "latents/s", "cores": ncore, "kind": "port",
+    return {"value": (tf / dt) / (485.04 / 8.0), "unit": "latents/s", "cores": ncore, "host_threads": os.cpu_count(), "kind": "port",
             "sample": f"oracle decode of 2 latents 48x2x6x10 ({tf:.2f} TFLOP, {dt:.2f} s = {tf / dt:.2f} TFLOP/s fp32), "
                       "scaled by FLOPs to the 704x1280 chunk (60.6 TFLOP per latent)"}
 
@@ -165,7 +165,7 @@ def cpu_baseline(cfg, L, model):
     want, dt = fullsize.run_block_oracle(case)
     torch.set_num_threads(ncpu)
     tf = block_flops_5b(L, cfg) / dt / 1e12
-    base = {"value": 1.0 / (dt * cfg["num_layers"]), "unit": "denoise-steps/sec", "cores": best, "kind": "port",
+    base = {"value": 1.0 / (dt * cfg["num_layers"]), "unit": "denoise-steps/sec", "cores": best, "host_threads": ncpu, "kind": "port",
             "sample": f"1 of {cfg['num_layers']} DiT blocks at L={L} (fp32, {dt:.2f} s = {tf:.2f} TFLOP/s on {best} of {ncpu} host threads), "
                       f"extrapolated x{cfg['num_layers']}; embed/head excluded; thread sweep on an L={Ls} block (TFLOP/s): "
                       + ", ".join(f"{t}: {v:.2f}" for t, v in sweep.items())
@@ -266,13 +266,13 @@ def _build_5b(args, rank, dev):
     return cfg, model, n_bcast
 
 
-def bench_tts(args, rank, world, dev):
+def bench_tts(args, rank, world, dev, built=None, emit=True):
     """BASELINE configs[3]: Yume-5B-720P SDE/TTS sampling (fastvideo/sample/sample_tts.py:694-868: eta 0.3, time_travel_step 2,
     interval 2 -> 74 model forwards per 50-step chunk), independent prompts sharded one per GPU (`index = (step-1)*world + rank`).
     A step = one SAMPLER step of that loop (its forward, its look-ahead forwards and updates); the window [warmup, warmup+steps)
     of the 50-step schedule is timed."""
     from yume_amd import framepack, sampling, synth
-    cfg, model, n_bcast = _build_5b(args, rank, dev)
+    cfg, model, n_bcast = built if built is not None else _build_5b(args, rank, dev)
     F, H, W, lfz, S, shift = 13, 44, 80, 8, 50, 7.0
     plan = framepack.pack_plan(F, H, W, lfz)
     g = torch.Generator(device=dev).manual_seed(3000 + rank)
@@ -288,28 +288,34 @@ def bench_tts(args, rank, world, dev):
                                                              return_state=True), world)
     assert torch.isfinite(latent).all()
     nfw = sampling.tts_forward_count(S, i0=w0, i1=w1)
+    res = None
     if rank == 0:
         k = w1 - w0
-        print(json.dumps({"metric": "SDE/TTS sampler-steps/sec (Yume-5B 720P, 33-frame latent)", "value": world * k / dt, "unit": "sampler-steps/sec",
+        res = ({"metric": "SDE/TTS sampler-steps/sec (Yume-5B 720P, 33-frame latent)", "value": world * k / dt, "unit": "sampler-steps/sec",
                           "n_gpus": world, "steps": k, "warmup": w0, "ms_per_step": dt / k * 1e3, "higher_is_better": True, "scaling": "weak",
                           "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
                           "config": {"workload": "Yume-5B-720P random-init, SDE (eta 0.3) + time-travel (step 2, interval 2) sampling of one "
                                                  "33-frame 704x1280 chunk, L=9460, one prompt per GPU", "tokens": plan.seq_len,
                                      "num_layers": cfg["num_layers"], "parallelism": f"dp{world} (independent prompts, replicated weights)"},
                           "model_forwards_timed": nfw, "forwards_per_s": world * nfw / dt, "forwards_per_50_step_chunk": sampling.tts_forward_count(S),
-                          "ms_per_forward": dt / nfw * 1e3, "weight_broadcast_collectives": n_bcast}), flush=True)
-    if world > 1:
+                          "ms_per_forward": dt / nfw * 1e3, "weight_broadcast_collectives": n_bcast,
+                          "model_tflop_per_forward": flops_fwd_5b(plan.seq_len, n=cfg["num_layers"]) / 1e12,
+                          "model_tflops_per_gpu": flops_fwd_5b(plan.seq_len, n=cfg["num_layers"]) / 1e12 * nfw / dt})
+        if emit:
+            print(json.dumps(res), flush=True)
+    if world > 1 and emit:
         dist.destroy_process_group()
+    return res
 
 
-def bench_longvideo(args, rank, world, dev):
+def bench_longvideo(args, rank, world, dev, built=None, emit=True):
     """BASELINE configs[4]: the FramePack long-video loop of fastvideo/sample/sample_5b.py:920-1097 — VAE encode of the conditioning
     clip, then `--chunks` (8) chunks of 2 s: `--steps` Euler steps each on [history | 8 noisy latents] (history grows by 8 latent
     frames per chunk: L 9460 ... 12545), VAE decode of the 8 new latents after every chunk. Everything is inside the timed region
     (the first chunk's encode included); one independent video per GPU. value = denoise steps of all ranks / time."""
     from yume_amd import framepack, sampling, synth
     from yume_amd.wan23.modules.vae2_2 import Wan2_2_VAE, WanVAE_
-    cfg, model, n_bcast = _build_5b(args, rank, dev)
+    cfg, model, n_bcast = built if built is not None else _build_5b(args, rank, dev)
     H, W, lfz, shift = 44, 80, 8, 7.0
     vcfg = synth.VAE_CFG_22
     with torch.device(dev):
@@ -332,9 +338,11 @@ def bench_longvideo(args, rank, world, dev):
     run(1, max(1, args.warmup))
     Ls.clear()
     hist, dt = _timed(lambda: run(args.chunks, args.steps), world)
+    res = None
     if rank == 0:
         nsteps = args.chunks * args.steps
-        print(json.dumps({"metric": "denoise-steps/sec (Yume-5B FramePack long video, VAE encode/decode per chunk in the timed region)",
+        tf = sum(flops_fwd_5b(l, n=cfg["num_layers"]) for l in Ls) / 1e12 * args.steps + args.chunks * 485.04 + 54.7
+        res = ({"metric": "denoise-steps/sec (Yume-5B FramePack long video, VAE encode/decode per chunk in the timed region)",
                           "value": world * nsteps / dt, "unit": "denoise-steps/sec", "n_gpus": world, "steps": nsteps, "warmup": args.warmup,
                           "ms_per_step": dt / nsteps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
                           "data": "synthetic",
@@ -342,12 +350,17 @@ def bench_longvideo(args, rank, world, dev):
                                                  "(the reference uses 50), 17-frame conditioning clip, Wan2.2 VAE encode + per-chunk decode",
                                      "tokens_per_chunk": Ls, "num_layers": cfg["num_layers"], "parallelism": f"dp{world} (independent videos, replicated weights)"},
                           "latents_per_s": world * args.chunks * lfz / dt, "final_history_latents": int(hist.shape[1]),
-                          "weight_broadcast_collectives": n_bcast}), flush=True)
-    if world > 1:
+                          "weight_broadcast_collectives": n_bcast,
+                          "model_tflop_timed": tf, "model_tflops_per_gpu": tf / dt,
+                          "model_tflop_note": "DiT forwards of every chunk at its own L + 485.04 per chunk decode + 54.7 for the 17-frame encode"})
+        if emit:
+            print(json.dumps(res), flush=True)
+    if world > 1 and emit:
         dist.destroy_process_group()
+    return res
 
 
-def bench_14b(args, rank, world, dev):
+def bench_14b(args, rank, world, dev, emit=True):
     """BASELINE configs[2]: Yume-I2V-14B-540P random-init, 65-frame 544x960 clip (latent [16,17,68,120] + y[20,...]),
     FramePack (rand_num_img=0.6, latent_frame_zero=9), CFG 5.0 -> two forwards per step, history re-noised each step
     (fastvideo/sample/sample.py:745-790). L = 27810 tokens, 2 x 1319.3 TFLOP per step."""
@@ -403,43 +416,94 @@ def bench_14b(args, rank, world, dev):
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     tmax = float(tmax.item())
+    res = None
     if rank == 0:
         ms = tmax / args.steps * 1e3
         tf = 2 * 1319.3 * (cfg["num_layers"] / 40.0)
-        print(json.dumps({"metric": "denoise-steps/sec (Yume-I2V-14B 540P, 65-frame latent, CFG)", "value": world * args.steps / tmax,
+        res = ({"metric": "denoise-steps/sec (Yume-I2V-14B 540P, 65-frame latent, CFG)", "value": world * args.steps / tmax,
                           "unit": "denoise-steps/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
                           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
                           "config": {"workload": "Yume-I2V-14B-540P random-init, latent 16x17x68x120 + y, FramePack lfz=9, L=27810, CFG 5.0 "
                                                  "(2 forwards/step), 50-step shift-3 schedule", "num_layers": cfg["num_layers"], "tokens": L},
                           "model_tflop_per_step": tf, "model_tflops_per_gpu": tf / (ms * 1e-3),
-                          "peak_mem_gb": torch.cuda.max_memory_allocated() / 1e9}), flush=True)
-    if world > 1:
+                          "peak_mem_gb": torch.cuda.max_memory_allocated() / 1e9})
+        if emit:
+            print(json.dumps(res), flush=True)
+    if world > 1 and emit:
         dist.destroy_process_group()
+    return res
+
+
+def other_workloads(args, dev, built):
+    """BASELINE configs[2], [3], [4] in the same process, behind the headline's timed region (each has its own barrier-bracketed timed
+    region; `python bench.py --workload X` runs one of them alone, at any N): {name: that workload's JSON object}."""
+    import copy
+    res = {}
+    for name, fn, kw, ov in (("tts", bench_tts, {"built": built}, dict(steps=4, warmup=2)),
+                             ("longvideo", bench_longvideo, {"built": built}, dict(steps=2, warmup=1, chunks=8)),
+                             ("14b", bench_14b, {}, dict(steps=3, warmup=1))):
+        a = copy.copy(args)
+        for k, v in ov.items():
+            setattr(a, k, v)
+        try:
+            t0 = time.perf_counter()
+            res[name] = fn(a, 0, 1, dev, emit=False, **kw)
+            res[name]["wall_s_incl_build"] = time.perf_counter() - t0
+        except Exception as e:  # noqa: BLE001 — never hide the headline behind a side workload
+            res[name] = {"failed": f"{type(e).__name__}: {e}"}
+        torch.cuda.empty_cache()
+    return res
+
+
+def full_step_parity(job, model, cfg):
+    """the WHOLE denoise step of BASELINE configs[1] — 30 live blocks + head at L = 9460 through WanModel.forward and
+    the Euler update of sample_5b.py:985-990 — on the device against oracle.dit.forward_wan23 (fp32, run as the subprocess `job` on the
+    host cores: oracle/step_job.py) on identical latent / timestep / text-embedding inputs and identical (hashed synthetic) weights.
+    -> (parity dict, cpu_baseline dict: the oracle's measured whole-step time instead of one block x 30)."""
+    from oracle import step_job
+    from yume_amd import synth
+    proc, path = job
+    synth.fill_module_hashed_(model, cfg, "wan23", step_job.SEED)            # the benchmarked module now holds the case's weights (bf16)
+    pred = step_job.device_forward("5b", model, "cond").cpu()
+    ref = step_job.finish_job(proc, path)
+    for f in (path, path + ".log"):
+        if os.path.exists(f):
+            os.remove(f)
+    lat, i = step_job.make_inputs("5b")["latent"], step_job.CASES["5b"]["i"]
+    p = step_job.stats(pred, ref["pred"])
+    u = step_job.stats(step_job.euler("5b", lat, pred, i), step_job.euler("5b", lat, ref["pred"], i))
+    par = {"pred_rel_l2": p["rel_l2"], "pred_max_abs": p["max_abs"], "pred_rms": p["ref_rms"], "latent_rel_l2": u["rel_l2"],
+           "latent_max_abs": u["max_abs"], "tolerance": "pred rel_l2 <= 3e-2, updated latent rel_l2 <= 2e-3 (DESIGN.md 5)",
+           "what": "one whole denoise step of configs[1] (30 live blocks + head, L=9460, sigma index 10 of 50, shift 7) + Euler update: device "
+                   "(bf16 weights, bf16 MFMA) vs CPU oracle (fp32) on identical inputs"}
+    tf = flops_fwd_5b(9460, n=cfg["num_layers"]) / 1e12
+    base = {"value": 1.0 / ref["seconds"], "unit": "denoise-steps/sec", "cores": ref["threads"], "host_threads": ref["host_threads"], "kind": "port",
+            "sample": f"ONE WHOLE denoise step (30 blocks + embeddings + head at L=9460, fp32): {ref['seconds']:.1f} s = {tf / ref['seconds']:.2f} TFLOP/s on "
+                      f"{ref['threads']} of {ref['host_threads']} host threads (+ {ref['gen_seconds']:.1f} s generating the weights, not counted), measured while "
+                      "the GPU ran the side workloads; kind 'port' = oracle/dit.py (restatement pinned to the reference): the GPU box has no "
+                      "reference tree to execute"}
+    return par, base
 
 
 def _self_launch(args, share):
     """`python bench.py --gpus N` outside torchrun: become the N-rank job (one process per GPU over RCCL, the launch the
     reference's scripts use — torchrun --nproc_per_node N fastvideo/sample/sample_5b.py, scripts/inference/sample_5b.sh; one
     process per GPU at sample_5b.py:1124-1134). Refuses by name when the node has fewer than N GPUs."""
-    import socket
     n = args.gpus
     have = torch.cuda.device_count()
     if have < n and not share:
         sys.exit(f"bench.py: --gpus {n} requested but this node shows {have} GPU(s): refusing to run {n} ranks on fewer devices "
                  "(a 1-rank run would print n_gpus: 1, not what was asked)")
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    # --standalone: the launcher's own c10d rendezvous picks a free port itself (no bind / close / reuse race of a pre-probed port)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1",
+           f"--nproc-per-node={n}", os.path.abspath(__file__)] + sys.argv[1:]
     sys.stdout.flush()
     os.execv(sys.executable, cmd)
 
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=None, help="ranks = GPUs of this node to use; default: the launcher's WORLD_SIZE, else 1")
     ap.add_argument("--steps", type=int, default=6)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--layers", type=int, default=0, help="debug only: override num_layers (result is then NOT the named config)")
@@ -452,7 +516,14 @@ def main():
                     help="5b = BASELINE configs[1] (the headline metric, default); 14b = configs[2] (Yume-I2V-14B-540P, 65-frame clip, CFG); "
                          "tts = configs[3] (SDE/TTS sampling, sampler steps); longvideo = configs[4] (FramePack chunks with VAE encode/decode)")
     ap.add_argument("--chunks", type=int, default=8, help="longvideo only: number of 2 s chunks (BASELINE: 8)")
+    ap.add_argument("--no-full-parity", action="store_true",
+                    help="skip the whole-step parity leg (30 blocks + head at L = 9460 against the CPU oracle: ~3-4 min of host time, "
+                         "run as a subprocess behind the timed region)")
+    ap.add_argument("--no-workloads", action="store_true",
+                    help="5b only: do not attach BASELINE configs[2] / [3] / [4] (14B CFG, SDE/TTS, long video) as `workloads` to the JSON line")
     args = ap.parse_args()
+    if args.gpus is None:
+        args.gpus = int(os.environ.get("WORLD_SIZE", "1"))          # `torchrun --nproc-per-node N bench.py` alone means N ranks
 
     share = os.environ.get("YUME_BENCH_SHARE_GPU", "0") == "1"   # test mode only: every rank on cuda:0, gloo instead of RCCL
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -582,6 +653,9 @@ def main():
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     tmax = float(tmax.item())
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()      # the last collective is behind us: the other ranks leave, rank 0 goes on to the host-side legs alone
 
     if rank == 0:
         ms_per_step = tmax / args.steps * 1e3
@@ -607,9 +681,13 @@ def main():
             "roofline_all_source": f"{n_extra} fully instrumented steps behind the timed region (HIP events around every kernel call); "
                                    "the timed steps bracket only the dominant group",
         }
-        if world == 1 and not args.no_cpu_baseline:
+        # cpu_baseline / parity are emitted by rank 0 at ANY world size (the CPU legs run on rank 0's host cores after the timed region;
+        # the other ranks have nothing left to do and leave)
+        job = None
+        if not args.no_cpu_baseline:
             try:
-                out["cpu_baseline"], out["parity"] = cpu_baseline(cfg, L, model)
+                out["cpu_baseline"], blk_par = cpu_baseline(cfg, L, model)
+                out["parity"] = {"block": blk_par}
             except Exception as e:  # noqa: BLE001 — a baseline failure must not hide the GPU number
                 out["cpu_baseline"] = {"value": None, "unit": "denoise-steps/sec", "cores": os.cpu_count(), "kind": "port",
                                        "sample": f"failed: {e}"}
@@ -618,9 +696,24 @@ def main():
                     vae_res["cpu_baseline"] = vae_cpu_baseline()
                 except Exception as e:  # noqa: BLE001
                     vae_res["cpu_baseline"] = {"value": None, "unit": "latents/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e}"}
+            if not args.no_full_parity and not args.layers:
+                try:                                  # the whole-step oracle: a subprocess on 32 host threads while the GPU runs the workloads below
+                    import tempfile
+                    from oracle import step_job
+                    job_out = os.path.join(tempfile.gettempdir(), f"yume_bench_step_{os.getpid()}.pt")
+                    job = (step_job.start_job("5b", "cond", job_out, threads=out["cpu_baseline"].get("cores") or 32), job_out)
+                except Exception as e:  # noqa: BLE001
+                    out.setdefault("parity", {})["full_step"] = {"failed": str(e)}
+        if world == 1 and not args.no_workloads and not args.layers:
+            out["workloads"] = other_workloads(args, dev, (cfg, model, n_bcast))
+        if job is not None:
+            try:
+                out.setdefault("parity", {})["full_step"], full_base = full_step_parity(job, model, cfg)
+                full_base["block_sample"] = out["cpu_baseline"]
+                out["cpu_baseline"] = full_base
+            except Exception as e:  # noqa: BLE001
+                out.setdefault("parity", {})["full_step"] = {"failed": f"{type(e).__name__}: {e}"}
         print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -1,0 +1,226 @@
+"""TEST INFRASTRUCTURE — the WHOLE denoise step against the oracle at full depth ("errors compound
+over 30-40 blocks ... full-model tolerances must be measured, not assumed").
+
+Cases (all: hashed synthetic weights, yume_amd.synth.HashedDitStateDict — the same rule evaluated on the host here and on the GPU by
+fill_module_hashed_, bit for bit; inputs from a seeded CPU generator):
+
+  5b        BASELINE.json configs[1] literally: Yume-5B (30 live blocks + head), latent [48,13,44,80], FramePack lfz=8, L = 9460,
+            77 text tokens, sigma index 10 of the 50-step shift-7 schedule, per-token timesteps (sample_5b.py:965-972), one forward
+            (wan23/modules/model.py:547-865) and the Euler update of the 8 new frames (sample_5b.py:985-990).
+  14b       Yume-I2V-14B (40 live blocks + head) at reduced length: latent [16,13,28,28] + y [20,13,28,28] (L = 2254), CLIP features,
+            rand_num_img 0.6 / lfz 9 (FramePack path), CFG 5.0 = two forwards (wan/modules/model.py:723-1013; sample.py:774-790).
+  5b_chain  the 5b case at a quarter of the area (latent [48,13,22,40], L = 2365) for multi-step drift records (tools/chain_drift.py).
+
+The CPU leg costs minutes (5b: 118.8 TFLOP in fp32), so it runs as a SUBPROCESS next to the GPU work:
+
+    python -m oracle.step_job --case 5b --which cond --out /tmp/x.pt [--threads 32]
+
+start_job()/finish_job() wrap that for tests/ and bench.py. The attention inside is oracle/fullsize.py::attention_fp32 (head-by-head
+fp32 exact softmax instead of one fp64 score matrix of all heads: 17 GB at L = 9460; a ~1e-6 change). Only tests/, bench.py's
+parity / cpu_baseline leg and tools/ may import this file."""
+import argparse
+import os
+import subprocess
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+SEED = 77
+CASES = {
+    "5b": dict(family="wan23", F=13, H=44, W=80, lfz=8, steps=50, shift=7.0, i=10, n_text=77),
+    "5b_chain": dict(family="wan23", F=13, H=22, W=40, lfz=8, steps=4, shift=7.0, i=0, n_text=77),
+    "14b": dict(family="wan", F=13, H=28, W=28, lfz=9, steps=50, shift=3.0, i=10, n_text=77, guide=5.0, rand_num_img=0.6),
+    # plumbing checks of this file on the build container (tests/test_step_job_cpu.py): 2-layer models of width 512
+    "tiny5b": dict(family="wan23", F=13, H=12, W=16, lfz=8, steps=50, shift=7.0, i=10, n_text=20, tiny=True),
+    "tiny14b": dict(family="wan", F=13, H=12, W=16, lfz=9, steps=50, shift=3.0, i=10, n_text=20, guide=5.0, rand_num_img=0.6, tiny=True),
+}
+
+
+def case_cfg(name):
+    from yume_amd import synth
+    if CASES[name].get("tiny"):
+        return synth.tiny_cfg(CASES[name]["family"])
+    return dict(synth.CFG_5B if CASES[name]["family"] == "wan23" else synth.CFG_14B)
+
+
+def make_inputs(name):
+    """seeded inputs of a case (CPU fp32): latent [C, F, H, W] = [history | noise], text embeddings (cond, uncond), 14B: y, clip_fea."""
+    c = CASES[name]
+    cfg = case_cfg(name)
+    g = torch.Generator().manual_seed(SEED + len(name))
+    Cx = cfg["out_dim"] if c["family"] == "wan" else cfg["in_dim"]
+    out = {"latent": torch.randn(Cx, c["F"], c["H"], c["W"], generator=g),
+           "cond": torch.randn(c["n_text"], cfg["text_dim"], generator=g),
+           "uncond": torch.randn(c["n_text"], cfg["text_dim"], generator=g)}
+    if c["family"] == "wan":
+        out["y"] = torch.randn(cfg["in_dim"] - cfg["out_dim"], c["F"], c["H"], c["W"], generator=g)
+        out["clip_fea"] = torch.randn(1, 257, 1280, generator=g)
+    return out
+
+
+def sigmas(name):
+    from . import sampler
+    c = CASES[name]
+    return [float(s) for s in sampler.get_sampling_sigmas(c["steps"], c["shift"])]
+
+
+def seq_len(name):
+    from yume_amd import framepack
+    c = CASES[name]
+    n_sel = c["F"] - 9 if c["family"] == "wan" else None      # wan/modules/model.py:781: the 14B file selects its branch with a literal 9
+    return framepack.pack_plan(c["F"], c["H"], c["W"], c["lfz"], n_sel)
+
+
+def euler(name, latent, pred, i):
+    """sample_5b.py:985-990 / sample.py:779-785: x_new = x + (sigma_{i+1} - sigma_i) * pred on the frames being denoised."""
+    c, sg = CASES[name], sigmas(name)
+    nxt = sg[i + 1] if i + 1 < len(sg) else 0.0
+    return latent[:, -c["lfz"]:] + (nxt - sg[i]) * pred[:, -c["lfz"]:]
+
+
+class _TimedSD:
+    """HashedDitStateDict with the generation time kept apart from the forward's own time."""
+
+    def __init__(self, sd):
+        self.sd, self.gen_s = sd, 0.0
+
+    def __getitem__(self, k):
+        t0 = time.time()
+        v = self.sd[k]
+        self.gen_s += time.time() - t0
+        return v
+
+    def __contains__(self, k):
+        return k in self.sd
+
+    def get(self, k, default=None):
+        return self[k] if k in self.sd else default
+
+
+@torch.no_grad()
+def oracle_forward(name, which, latent=None, i=None, threads=None):
+    """one reference-restatement forward of the case on the host -> (pred fp32 [Cout, lfz, H, W], forward seconds, weight-generation seconds)."""
+    from yume_amd import synth
+    from . import dit as odit
+    from . import fullsize
+    c = CASES[name]
+    cfg = case_cfg(name)
+    if threads:
+        torch.set_num_threads(threads)
+    inp = make_inputs(name)
+    latent = inp["latent"] if latent is None else latent
+    i = c["i"] if i is None else i
+    plan = seq_len(name)
+    sg = sigmas(name)
+    sd = _TimedSD(synth.HashedDitStateDict(cfg, c["family"], SEED))
+    orig = odit.attention
+    odit.attention = fullsize.attention_fp32
+    try:
+        t0 = time.time()
+        if c["family"] == "wan23":
+            t = torch.cat([torch.zeros(plan.n_hist_tok, dtype=torch.float64),
+                           torch.full((plan.n_new_tok,), sg[i] * 1000.0, dtype=torch.float64)]).unsqueeze(0)
+            pred = odit.forward_wan23(sd, cfg, latent, t, inp[which], plan.seq_len, c["lfz"], True)
+        else:
+            t = torch.tensor([sg[i] * 1000.0])
+            pred = odit.forward_wan(sd, cfg, latent, t, inp[which], plan.seq_len, inp["clip_fea"][0], inp["y"],
+                                    rand_num_img=c["rand_num_img"], latent_frame_zero=c["lfz"])
+        dt = time.time() - t0
+    finally:
+        odit.attention = orig
+    return pred, dt - sd.gen_s, sd.gen_s
+
+
+# ------------------------------------------------------------------------------------------------ device side (tests / bench)
+def build_device_model(name, dev="cuda", dtype=torch.bfloat16):
+    """the drop-in WanModel of the case on the GPU holding the hashed weights; cast to bf16 as the sampling scripts do
+    (sample_5b.py:1241, sample.py:1021) — the oracle keeps fp32 weights, so the figure includes the weight rounding."""
+    from yume_amd import synth
+    c, cfg = CASES[name], case_cfg(name)
+    if c["family"] == "wan23":
+        from yume_amd.wan23.modules.model import WanModel
+        with torch.device(dev):
+            m = WanModel(**cfg)
+    else:
+        from yume_amd.wan.modules.model import WanModel
+        with torch.device(dev):
+            m = WanModel(**cfg).attach_pyramid()
+    synth.fill_module_hashed_(m, cfg, c["family"], SEED)
+    return m.to(dtype).eval().requires_grad_(False)
+
+
+@torch.no_grad()
+def device_forward(name, model, which, latent=None, i=None):
+    c = CASES[name]
+    dev = next(model.parameters()).device
+    inp = make_inputs(name)
+    latent = (inp["latent"] if latent is None else latent).to(dev)
+    i = c["i"] if i is None else i
+    plan, sg = seq_len(name), sigmas(name)
+    if c["family"] == "wan23":
+        t = torch.cat([torch.zeros(plan.n_hist_tok, dtype=torch.float64),
+                       torch.full((plan.n_new_tok,), sg[i] * 1000.0, dtype=torch.float64)]).unsqueeze(0).to(dev)
+        return model([latent], t=t, context=[inp[which].to(dev)], seq_len=plan.seq_len, latent_frame_zero=c["lfz"], flag=True)[0]
+    t = torch.tensor([sg[i] * 1000.0], device=dev)
+    return model([latent], t=t, context=[inp[which].to(dev)], seq_len=plan.seq_len, clip_fea=inp["clip_fea"].to(dev), y=[inp["y"].to(dev)],
+                 rand_num_img=c["rand_num_img"], latent_frame_zero=c["lfz"])[0]
+
+
+def weights_agree(name, model, keys=("blocks.0.ffn.0.weight", "blocks.1.self_attn.q.weight", "head.head.weight", "blocks.0.modulation")):
+    """the device model holds the bf16 rounding of exactly the values the host oracle generates (checked on a few tensors)."""
+    from yume_amd import synth
+    c, cfg = CASES[name], case_cfg(name)
+    sd = synth.HashedDitStateDict(cfg, c["family"], SEED)
+    params = dict(model.named_parameters())
+    return all(torch.equal(params[k].detach().cpu(), sd[k].to(params[k].dtype)) for k in keys)
+
+
+def stats(got, want):
+    d = got.double() - want.double()
+    return {"rel_l2": (d.norm() / want.double().norm()).item(), "max_abs": d.abs().max().item(),
+            "ref_rms": want.double().pow(2).mean().sqrt().item()}
+
+
+# ------------------------------------------------------------------------------------------------ subprocess plumbing
+def start_job(name, which, out, threads=32):
+    """launch `python -m oracle.step_job` for one forward; returns the Popen (stdout/stderr -> <out>.log)."""
+    env = dict(os.environ)
+    env["OMP_NUM_THREADS"] = str(threads)
+    env["MKL_NUM_THREADS"] = str(threads)
+    env["CUDA_VISIBLE_DEVICES"] = ""
+    env["HIP_VISIBLE_DEVICES"] = ""
+    log = open(out + ".log", "w")
+    return subprocess.Popen([sys.executable, "-m", "oracle.step_job", "--case", name, "--which", which, "--out", out, "--threads", str(threads)],
+                            cwd=ROOT, env=env, stdout=log, stderr=subprocess.STDOUT)
+
+
+def finish_job(proc, out, timeout=1500):
+    rc = proc.wait(timeout=timeout)
+    if rc != 0:
+        tail = open(out + ".log").read()[-2000:]
+        raise RuntimeError(f"oracle.step_job failed (rc {rc}): {tail}")
+    return torch.load(out, weights_only=False)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--case", required=True, choices=sorted(CASES))
+    ap.add_argument("--which", default="cond", choices=["cond", "uncond"])
+    ap.add_argument("--out", required=True)
+    ap.add_argument("--threads", type=int, default=32)
+    a = ap.parse_args()
+    threads = max(1, min(a.threads, os.cpu_count() or 1))
+    pred, secs, gen = oracle_forward(a.case, a.which, threads=threads)
+    torch.save({"pred": pred, "seconds": secs, "gen_seconds": gen, "threads": threads, "case": a.case, "which": a.which,
+                "host_threads": os.cpu_count()}, a.out + ".tmp")
+    os.replace(a.out + ".tmp", a.out)
+    print(f"{a.case}/{a.which}: forward {secs:.1f} s + weights {gen:.1f} s on {threads} threads; pred rms {pred.pow(2).mean().sqrt():.4f}")
+
+
+if __name__ == "__main__":
+    main()

@@ -73,7 +73,7 @@ def test_bench_gpus_2_launches_two_ranks_itself():
     fastvideo/sample/sample_5b.py:1124-1134, index = (step-1)*world + rank at :782-785). The single-GPU test box has one device, so the two
     ranks share cuda:0 and talk gloo (YUME_BENCH_SHARE_GPU=1, test mode); everything else is bench's own N > 1 control flow: per-rank
     chains, weight replication from rank 0, barrier-bracketed timing, max over ranks, one JSON line from rank 0."""
-    r, line = _run_bench(["--gpus", "2", "--layers", "1", "--steps", "2", "--warmup", "1", "--no-vae", "--no-cpu-baseline"],
+    r, line = _run_bench(["--gpus", "2", "--layers", "1", "--steps", "2", "--warmup", "1", "--no-vae"],
                          {"YUME_BENCH_SHARE_GPU": "1"})
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert line is not None, r.stdout[-2000:]
@@ -82,6 +82,9 @@ def test_bench_gpus_2_launches_two_ranks_itself():
     assert line["weight_broadcast_collectives"] > 0
     assert line["config"]["parallelism"].startswith("dp2")
     assert line["value"] > 0 and abs(line["value"] - 2 * 2 / (line["ms_per_step"] * 2e-3)) < 1e-6 * line["value"]
+    # an N > 1 line is complete: rank 0 emits the CPU baseline and the parity figure at any world size
+    assert line["cpu_baseline"]["value"] > 0 and line["cpu_baseline"]["kind"] == "port" and line["cpu_baseline"]["host_threads"] >= line["cpu_baseline"]["cores"]
+    assert line["parity"]["block"]["rel_l2"] <= 1e-2
 
 
 @pytest.mark.skipif(torch.cuda.device_count() >= 2, reason="a multi-GPU box runs it for real")

@@ -118,6 +118,99 @@ def make_tensor(key, shape, seed, dim):
     return _uniform(shape, math.sqrt(6.0 / (fan_in + fan_out)), g)
 
 
+_M64 = (1 << 64) - 1
+
+
+def _s64(v):
+    """the 64-bit pattern v as the signed value torch's int64 holds."""
+    v &= _M64
+    return v - (1 << 64) if v >= (1 << 63) else v
+
+
+def hashed_uniform(key, shape, seed, a, device="cpu", chunk=None):
+    """Uniform(-a, a) fp32 values that depend only on (seed, key, flat index): a splitmix64-style integer hash evaluated with
+    torch's int64 elementwise kernels (wrapping multiply, masked shifts), 23 hash bits -> (2u + 1) * 2^-23 - 1 exactly, one
+    rounding for the scale. The same integer and float operations run on the host (all cores, cache-sized chunks, in place:
+    ~0.6 G values/s on 8 cores — the sequential CPU generator behind make_tensor takes minutes for a 5B / 14B parameter set)
+    and on the GPU, so a full-size weight set can be produced independently on both sides, bit for bit
+    (tests/test_synth_hash.py pins the values against a numpy uint64 evaluation)."""
+    n = 1
+    for s in shape:
+        n *= s
+    dev = torch.device(device)
+    if chunk is None:
+        chunk = (1 << 18) if dev.type == "cpu" else (1 << 26)
+    out = torch.empty(n, dtype=torch.float32, device=dev)
+    base = ((seed * 1000003 + zlib.crc32(key.encode())) & 0x7FFFFFFF) * 0xD1B54A32D192ED03
+    idx = torch.arange(0, min(chunk, n), dtype=torch.int64, device=dev)
+    x, t = torch.empty_like(idx), torch.empty_like(idx)
+    for i0 in range(0, n, chunk):
+        m = min(n, i0 + chunk) - i0
+        xx, tt = x[:m], t[:m]
+        torch.mul(idx[:m], _s64(0x9E3779B97F4A7C15), out=xx)
+        xx.add_(_s64(base + i0 * 0x9E3779B97F4A7C15))
+        for sh, mul in ((30, 0xBF58476D1CE4E5B9), (27, 0x94D049BB133111EB)):
+            torch.bitwise_right_shift(xx, sh, out=tt)
+            tt.bitwise_and_((1 << (64 - sh)) - 1)              # logical shift: int64's >> is arithmetic
+            xx.bitwise_xor_(tt)
+            xx.mul_(_s64(mul))
+        torch.bitwise_right_shift(xx, 31, out=tt)
+        tt.bitwise_and_((1 << 33) - 1)
+        xx.bitwise_xor_(tt)
+        xx.bitwise_right_shift_(41).bitwise_and_((1 << 23) - 1)
+        o = out[i0:i0 + m]
+        o.copy_(xx)
+        o.mul_(2.0 ** -22).add_(2.0 ** -23 - 1.0).mul_(a)
+    return out.view(shape)
+
+
+def make_tensor_hashed(key, shape, seed, dim, device="cpu"):
+    """make_tensor's per-key scale rules; the large xavier-uniform matrices (every Linear / patch-embed weight of the blocks)
+    come from hashed_uniform, the small tensors (biases, norm weights, modulation, N(0, .02) embeddings) from make_tensor."""
+    leaf = key.split(".")[-1]
+    small = (leaf in ("modulation", "bias") or "norm" in key or key.startswith(("img_emb.proj.0", "img_emb.proj.4"))
+             or key.startswith(("text_embedding", "time_embedding", "head.head")))
+    if small:
+        return make_tensor(key, shape, seed, dim).to(device)
+    fan_in = 1
+    for s in shape[1:]:
+        fan_in *= s
+    return hashed_uniform(key, shape, seed, math.sqrt(6.0 / (fan_in + shape[0])), device)
+
+
+class HashedDitStateDict:
+    """A read-only mapping key -> fp32 tensor over dit_param_shapes(cfg, family) that GENERATES a tensor on every access
+    (make_tensor_hashed) and keeps nothing: the CPU oracle walks a 5B / 14B parameter set block by block with one block's
+    weights alive at a time (a 14B fp32 state_dict is 55 GB), and the device model is filled tensor by tensor from the same
+    rule evaluated on the GPU (fill_module_hashed_)."""
+
+    def __init__(self, cfg, family, seed=0, pyramid=("_2x", "_4x", "_8x", "_16x", "_2x_f"), device="cpu"):
+        self.shapes = dit_param_shapes(cfg, family, pyramid)
+        self.cfg, self.family, self.seed, self.device = cfg, family, seed, device
+
+    def __getitem__(self, k):
+        return make_tensor_hashed(k, self.shapes[k], self.seed, self.cfg["dim"], self.device)
+
+    def __contains__(self, k):
+        return k in self.shapes
+
+    def get(self, k, default=None):
+        return self[k] if k in self.shapes else default
+
+    def keys(self):
+        return self.shapes.keys()
+
+
+@torch.no_grad()
+def fill_module_hashed_(model, cfg, family, seed=0):
+    """every parameter of a device-resident WanModel <- HashedDitStateDict value of its key, generated on the parameter's device."""
+    dev = next(model.parameters()).device
+    sd = HashedDitStateDict(cfg, family, seed, device=dev)
+    for key, p in model.named_parameters():
+        p.copy_(sd[key].to(p.dtype))
+    return model
+
+
 def make_dit_state_dict(cfg, family, seed=0, pyramid=("_2x", "_4x", "_8x", "_16x", "_2x_f"), dtype=torch.float32,
                         device="cpu"):
     sd = {}
