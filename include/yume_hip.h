@@ -8,7 +8,9 @@
  *
  * Conventions
  *   - every pointer is a DEVICE pointer into memory owned by the caller (torch-allocated);
- *     the library never allocates or frees device memory.
+ *     the library never allocates or frees device memory. The only device memory it keeps a
+ *     pointer to between calls is the ticket-counter workspace the caller registers with
+ *     yume_counter_workspace_init (below); without one, every kernel runs a ticket-free schedule.
  *   - shapes are element counts, strides/leading dimensions are in ELEMENTS of the buffer type.
  *   - bf16 buffers are passed as `const void*` / `void*` (raw 16-bit brain floats).
  *   - `stream` is a hipStream_t passed as void* (NULL = the null stream). No entry point
@@ -36,10 +38,21 @@ extern "C" {
 /* ---- library info ------------------------------------------------------------------- */
 const char* yume_last_error(void);
 /* ABI version of this header; bumped on any signature change (yume_amd/_lib.py refuses a library that reports another one). */
-#define YUME_ABI_VERSION 5
+#define YUME_ABI_VERSION 6
 int yume_abi_version(void);
 /* name of the gfx target the kernels were compiled for ("gfx950"). */
 const char* yume_target_arch(void);
+
+/* ---- caller-owned ticket-counter workspace --------------------------------------------------
+ * Kernels that hand out work by ticket (the tails of long convolutions; the persistent attention kernel) draw their counters from a
+ * buffer the CALLER owns: yume_counter_workspace_bytes() bytes, 64-byte aligned, registered once per device with
+ * yume_counter_workspace_init(ptr, bytes, stream) — the call zeroes it on `stream` — and valid until it is replaced or unregistered
+ * (ptr = NULL). Invariant: the buffer holds zeros whenever no launch is using it (the last workgroup of a launch to touch its 64-byte
+ * counter set writes the zeros back), so launches need no memset and can be captured into a hipGraph. A set is shared by two launches
+ * only if 256 ticketed launches of one device are in flight at once. Without a registered buffer the ticketed kernels keep their static
+ * schedules (same results). The registration is per process and per device (the calling thread's current device). */
+int64_t yume_counter_workspace_bytes(void);
+int yume_counter_workspace_init(void* ptr, int64_t bytes, void* stream);
 
 /* ---- fused LayerNorm + modulate  ---------------------------------------------------------
  * replaces: wan23/modules/model.py:300-301,309-310 (norm1/norm2 + `*(1+scale)+shift`),

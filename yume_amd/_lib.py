@@ -18,6 +18,8 @@ SIGNATURES = {
     "yume_last_error": [],
     "yume_abi_version": [],
     "yume_target_arch": [],
+    "yume_counter_workspace_bytes": [],
+    "yume_counter_workspace_init": [_P, _L, _P],
     "yume_adaln_modulate": [_P, _L, _L, _L, _F, _P, _P, _L, _P, _I, _P, _L, _I, _P],
     "yume_gemm_bf16": [_P, _L, _P, _L, _P, _L, _L, _L, _I, _P, _L, _P, _L, _P, _P, _L, _L, _I, _P],
     "yume_rmsnorm_f32": [_P, _L, _L, _L, _F, _P, _P, _L, _P],
@@ -48,10 +50,11 @@ SIGNATURES = {
     "yume_frames_u8_trunc": [_P, _L, _L, _L, _L, _P, _P],
     "yume_vae_unpack_output": [_P, _L, _L, _L, _L, _L, _I, _P, _P, _F, _F, _P, _P],
 }
-_RES = {"yume_last_error": c_char_p, "yume_target_arch": c_char_p, "yume_gemm_splitk_workspace_bytes": c_int64, "yume_attn_workspace_bytes": c_int64}
+_RES = {"yume_last_error": c_char_p, "yume_target_arch": c_char_p, "yume_gemm_splitk_workspace_bytes": c_int64, "yume_attn_workspace_bytes": c_int64,
+        "yume_counter_workspace_bytes": c_int64}
 
 _lib = None
-ABI_VERSION = 5          # must equal YUME_ABI_VERSION in include/yume_hip.h; bumped whenever an argument list changes
+ABI_VERSION = 6          # must equal YUME_ABI_VERSION in include/yume_hip.h; bumped whenever an argument list changes
 
 
 def load():

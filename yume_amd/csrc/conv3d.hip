@@ -208,6 +208,8 @@ extern "C" int yume_conv3d_cl(const void* x, const void* cache, int64_t ldc, int
     YUME_REQUIRE(Tin > 0 && Hin > 0 && Win > 0 && Cin > 0 && Cout > 0 && To > 0 && Ho > 0 && Wo > 0, "conv3d_cl: empty shape");
     YUME_REQUIRE((Cin % 8) == 0 && (ldc % 8) == 0 && ldc >= Cin, "conv3d_cl: Cin=%lld and ldc=%lld must be multiples of 8", (long long)Cin, (long long)ldc);
     YUME_REQUIRE((Cout % 4) == 0 && (ldo % 4) == 0, "conv3d_cl: Cout and ldo must be multiples of 4");
+    YUME_REQUIRE(ldo >= (epi == 17 ? Cout / 2 : Cout), "conv3d_cl: ldo=%lld is smaller than the %lld output channels of a row", (long long)ldo,
+                 (long long)(epi == 17 ? Cout / 2 : Cout));
     YUME_REQUIRE(kt >= 1 && kh >= 1 && kw >= 1 && st >= 1 && sh >= 1 && sw >= 1 && pt >= 0 && pt <= 2, "conv3d_cl: bad kernel geometry");
     const int64_t Ktrue = (int64_t)kt * kh * kw * Cin;
     const int64_t Kp = (Ktrue + BK - 1) / BK * BK;

@@ -159,7 +159,7 @@ __global__ __launch_bounds__(256, 1) void conv_halo16_kernel(Params p) {
             if (4 * l4 + q < p.cout) b4[q] = p.bias[4 * l4 + q];
     }
     const int ho = h0 + wave;
-    if (ho < p.H && 4 * l4 < p.ldo) {
+    if (ho < p.H && 4 * l4 < p.cout) {            // whole groups of 4 channels (cout % 4 == 0): the row padding [cout, ldo) of `out` is not touched
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
             const int wo = w0 + 16 * m + l15;
@@ -168,7 +168,6 @@ __global__ __launch_bounds__(256, 1) void conv_halo16_kernel(Params p) {
             u32x2 o;
             o[0] = pack_bf16x2(v[0], v[1]);
             o[1] = pack_bf16x2(v[2], v[3]);
-            // channels >= cout are zero weights + zero bias: they store the zeros the channel padding of `out` holds anyway
             *reinterpret_cast<u32x2*>(p.out + (((int64_t)to * p.H + ho) * p.W + wo) * p.ldo + 4 * l4) = o;
         }
     }
@@ -180,7 +179,7 @@ inline bool applies(int64_t Cin, int64_t Cout, int kt, int kh, int kw, int st, i
     static const bool on = [] { const char* v = getenv("YUME_CONV_HALO"); return !v || atoi(v) != 0; }();
     if (!on || epi != YUME_EPI_BF16 || ups || st != 1 || sh != 1 || sw != 1) return false;
     if (kt != 3 || kh != 3 || kw != 3 || pt != 2 || ph != 1 || pw != 1 || Cout > 16 || (Cin % 64) != 0) return false;
-    if (Ho != Hin || Wo != Win || (ldo != 8 && ldo != 16) || (ldc % 8) != 0 || (ldw % 8) != 0) return false;
+    if (Ho != Hin || Wo != Win || (ldo != 8 && ldo != 16) || ldo < Cout || (Cout % 4) != 0 || (ldc % 8) != 0 || (ldw % 8) != 0) return false;
     if (Hin * Win * ldc * 2 >= 0x7fffff00ll) return false;
     return Ho * Wo >= 64 * 1024;           // the full-resolution head; small frames stay on the GEMM kernels
 }

@@ -14,8 +14,7 @@
 // Everything else — LDS images, fragment reads, gap plan, epilogues — is gemm_w4.hpp's.
 #pragma once
 #include "gemm_w4.hpp"
-#include <atomic>
-#include <mutex>
+#include "counters.hpp"
 
 namespace gemm_w4 {
 
@@ -28,11 +27,13 @@ struct ConvW4 {
     int ups;                       // the conv reads the nearest-2x upsampled view of x (Ho = 2 Hin, Wo = 2 Win)
     // Long launches (>= 8 rounds of tiles): the XCDs of one chip do not run the same code equally fast (the starts of a round drift apart
     // by about a tile time per 12 rounds, profiles/r3_gemm_w4.md section 7), and a static split leaves the fast ones idle at the end. The
-    // last `dyn` tiles of every XCD's chunk are handed out by ticket (steal[xcd], zeroed before the launch): first to the XCD's own
-    // workgroups, then to workgroups of XCDs whose own tickets have run out — among them 32 surplus workgroups per XCD that exist only
-    // to steal. nullptr: the static split.
+    // last `dyn` tiles of every XCD's chunk are handed out by ticket (steal[xcd]): first to the XCD's own workgroups, then to workgroups
+    // of XCDs whose own tickets have run out — among them 32 surplus workgroups per XCD that exist only to steal. steal = one set of the
+    // caller's counter workspace (counters.hpp: zeros between launches; steal[8] counts the workgroups that have drawn, the last of the
+    // `nticket` puts the zeros back). nullptr: the static split.
     int* steal;
     int dyn;
+    int nticket;
 };
 
 // wave-uniform walk of the K tiles (the tile to STAGE): order (dt, channel tile, dh, dw)
@@ -217,6 +218,14 @@ __global__ __launch_bounds__(NTHR_W4, 1) void conv_w4_kernel(Problem p, ConvW4 c
                 const int dy = min(cy, cv.dyn), ty = atomicAdd(&cv.steal[y], 1);
                 if (ty < dy) got = sy + cy - dy + ty;
             }
+            // The counter set is caller-owned memory that holds zeros between launches (counters.hpp): the LAST workgroup to have drawn
+            // its tickets — nobody touches the set after it — puts the zeros back. No memset in front of the launch, nothing shared
+            // with the next launch that is handed this set.
+            __threadfence();
+            if (atomicAdd(&cv.steal[8], 1) == cv.nticket - 1) {
+#pragma unroll
+                for (int k = 0; k < 9; ++k) atomicExch(&cv.steal[k], 0);
+            }
             *slot = got;
         }
         __syncthreads();
@@ -271,32 +280,22 @@ inline int launch_conv_w4(int epi, const Problem& p128, const ConvW4& cv, const 
     ConvW4 c = cv;
     c.steal = nullptr;
     c.dyn = 0;
+    c.nticket = 0;
     unsigned grid = (unsigned)ntile;
     static const bool steal_on = [] { const char* v = getenv("YUME_CONV_STEAL"); return !v || atoi(v) != 0; }();
     if (steal_on && ntile >= 8 * 256) {
-        // ticket counters: a ring of 64 sets per device (a set is in use for one launch; 64 convolutions of one process in flight at once
-        // on one device would be needed for two launches to meet on a set)
-        constexpr int SETS = 64, MAXDEV = 16;
-        static int* ring[MAXDEV] = {};
-        static std::atomic<unsigned> next[MAXDEV];
-        static std::mutex ring_mutex;                      // (host threads may launch convolutions concurrently)
-        int dev = 0;
-        if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < MAXDEV) {
-            int* mine;
-            {
-                std::lock_guard<std::mutex> lock(ring_mutex);
-                if (!ring[dev] && hipMalloc(&ring[dev], SETS * 8 * sizeof(int)) != hipSuccess) ring[dev] = nullptr;
-                mine = ring[dev];
-            }
-            if (mine) {
-                c.steal = mine + 8 * (next[dev].fetch_add(1u) % SETS);
-                c.dyn = 96;
-                if (hipMemsetAsync(c.steal, 0, 8 * sizeof(int), st) != hipSuccess) {
-                    c.steal = nullptr;
-                    c.dyn = 0;
-                } else {
-                    grid += 8 * 32;
-                }
+        // ticket counters: one 64-byte set of the caller's counter workspace (yume_counter_workspace_init; counters.hpp) — the library
+        // allocates nothing. Without a registered workspace the launch keeps its static tile order.
+        c.steal = yume_counters::next_set();
+        if (c.steal) {
+            c.dyn = 96;
+            grid += 8 * 32;
+            c.nticket = 0;                                 // workgroups that will draw a ticket: per XCD the last `dyn` tiles + the surplus ids
+            for (int x = 0; x < 8; ++x) {
+                int sx, cx;
+                xcd_chunk(ntile, x, sx, cx);
+                const int blocks_x = ((int)grid - x + 7) / 8, first = cx > c.dyn ? cx - c.dyn : 0;
+                c.nticket += blocks_x - first;
             }
         }
     }

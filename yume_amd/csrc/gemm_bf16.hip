@@ -6,23 +6,6 @@
 using namespace gemm_core;
 
 namespace {
-// side stream + fork / join events of the row-split launches (YUME_GEMM_SPLIT_STREAMS=1), one set per device, created on first use
-struct SideStream { hipStream_t s; hipEvent_t fork, join; };
-SideStream* side_stream() {
-    static const bool on = [] { const char* v = getenv("YUME_GEMM_SPLIT_STREAMS"); return v && atoi(v) != 0; }();
-    if (!on) return nullptr;
-    static SideStream per_dev[16];
-    static bool made[16] = {};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
-    if (!made[dev]) {
-        SideStream& x = per_dev[dev];
-        if (hipStreamCreateWithFlags(&x.s, hipStreamNonBlocking) != hipSuccess) return nullptr;
-        if (hipEventCreateWithFlags(&x.fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&x.join, hipEventDisableTiming) != hipSuccess) return nullptr;
-        made[dev] = true;
-    }
-    return &per_dev[dev];
-}
 // variant 0 (automatic) takes the one-wave-per-SIMD kernel (gemm_w4.hpp) wherever it took the 8-wave 256x256 kernel; YUME_GEMM_W4=0 keeps the latter
 bool w4_auto() {
     static const bool on = [] { const char* v = getenv("YUME_GEMM_W4"); return !v || atoi(v) != 0; }();
@@ -63,24 +46,8 @@ extern "C" int yume_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t
                                       row_idx ? row_idx + M_main : nullptr,
                                       outT ? reinterpret_cast<unsigned short*>(outT) + M_main : nullptr, ldt, n_split, 1, s2);
             };
-            // The remainder launch (a few hundred rows on the 128x128 kernel) fills ~a third of the CUs for as long as a whole round of the
-            // main launch takes; the two touch disjoint output rows. YUME_GEMM_SPLIT_STREAMS=1: it goes to a side stream first (fork / join
-            // by events, graph-capturable) so that its workgroups and the main launch's share the chip instead of running back to back.
-            SideStream* ss = side_stream();
-            if (ss) {
-                hipStream_t st = (hipStream_t)stream;
-                if (hipEventRecord(ss->fork, st) != hipSuccess || hipStreamWaitEvent(ss->s, ss->fork, 0) != hipSuccess) {
-                    yume_set_error("gemm_bf16: side stream fork failed");
-                    return YUME_ELAUNCH;
-                }
-                int rc = remainder((void*)ss->s);
-                if (rc != YUME_OK) return rc;
-                if (hipEventRecord(ss->join, ss->s) != hipSuccess) { yume_set_error("gemm_bf16: side stream join failed"); return YUME_ELAUNCH; }
-                rc = yume_gemm_bf16(A, lda, W, ldw, bias, M_main, N, K, epi, out, ldo, gate, gate_stride, row_idx, outT, ldt, n_split, w4_auto() ? 3 : 2, stream);
-                if (rc != YUME_OK) return rc;
-                if (hipStreamWaitEvent(st, ss->join, 0) != hipSuccess) { yume_set_error("gemm_bf16: side stream join failed"); return YUME_ELAUNCH; }
-                return YUME_OK;
-            }
+            // (r2/r3 experiment, removed in r4: the remainder on a library-owned side stream, fork / join by events, bought 30 us of overlap
+            // and paid most of it back in the two event hops — and made the library own a stream. Both launches go to the caller's stream.)
             int rc = yume_gemm_bf16(A, lda, W, ldw, bias, M_main, N, K, epi, out, ldo, gate, gate_stride, row_idx, outT, ldt, n_split,
                                     w4_auto() ? 3 : 2, stream);
             if (rc != YUME_OK) return rc;

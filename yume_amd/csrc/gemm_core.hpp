@@ -782,7 +782,7 @@ __device__ __forceinline__ void tile_origin(const Problem& p, int wg, int& m0, i
     n0 = ((wg % width) / gsz) * 256;
 }
 // XCD x walks its own contiguous chunk [start, start + count) of that order (block b runs on XCD b % 8)
-__device__ __forceinline__ void xcd_chunk(int nwg, int xcd, int& start, int& count) {
+__host__ __device__ __forceinline__ void xcd_chunk(int nwg, int xcd, int& start, int& count) {
     const int q = nwg >> 3, r = nwg & 7;
     start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
     count = q + (xcd < r ? 1 : 0);

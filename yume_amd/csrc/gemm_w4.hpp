@@ -387,8 +387,10 @@ __device__ __forceinline__ void w4_epilogue(const Problem& p, const Epilogue& e,
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
             TRACE_STAMP(4);
             if constexpr (EPI == EPI_BF16_TSPLIT) {
-                // out row m=(t,hw), col n=(j,c) -> out[((2t+j)*HW + hw), c]: a tile lies in one frame t and one channel half j (the caller checked
-                // HW % 256 == 0 and (N/2) % 256 == 0), so its rows stay consecutive
+                // out row m=(t,hw), col n=(j,c) -> out[((2t+j)*HW + hw), c]: a tile lies in ONE frame t and one channel half j, so its rows stay
+                // consecutive. The contract (conv_w4_kernel): a tile never spans two frames — a frame takes ceil(HW / 256) tiles, m0 is the
+                // tile's first row inside the whole matrix and p.M the END OF ITS FRAME ((t+1)*HW), so min(256, p.M - m0) also trims the ragged
+                // last tile of a frame whose HW is not a multiple of 256; (N/2) % 256 == 0 is checked by the caller
                 const int ch = p.N >> 1, jh = n0 >= ch ? 1 : 0, t = m0 / e.hw;
                 w4_store_image(smem, reinterpret_cast<unsigned short*>(e.out), e.ldo, m0 + (t + jh) * e.hw, min(256, p.M - m0), n0 - jh * ch, 256);
             } else {
@@ -574,7 +576,7 @@ __global__ __launch_bounds__(NTHR_W4, 1) void gemm_w4_kernel(Problem p, PlainA a
     TRACE_STAMP(2);
 }
 
-// shapes the kernel takes: at least two K tiles; 32-bit per-lane source offsets inside a tile's 256 rows
+// shapes the kernel takes: at least THREE K tiles (two are in flight before the loop, the loop body stages a third); 32-bit per-lane source offsets inside a tile's 256 rows
 inline bool w4_applies(const Problem& p, int64_t lda, int epi) {
     if (p.K < 3 * BK) return false;
 #ifdef W4_EXPERIMENT

@@ -2,7 +2,9 @@
 // sinusoidal timestep embedding, small-M fp32 linear (time MLP on R distinct timesteps),
 // patch gather (im2col for stride==kernel Conv3d), unpatchify, cast/pad, transpose.
 #include "common.hpp"
+#include "counters.hpp"
 #include <string.h>
+#include <atomic>
 
 // ---- error plumbing -----------------------------------------------------------------------
 static thread_local char g_err[512] = "";
@@ -17,6 +19,42 @@ void yume_set_error(const char* fmt, ...) {
 extern "C" const char* yume_last_error(void) { return g_err; }
 extern "C" int yume_abi_version(void) { return YUME_ABI_VERSION; }
 extern "C" const char* yume_target_arch(void) { return "gfx950"; }
+
+// ---- caller-owned ticket-counter workspace (counters.hpp) -------------------------------------------
+namespace yume_counters {
+constexpr int MAXDEV = 64;
+static std::atomic<int*> g_base[MAXDEV];
+static std::atomic<unsigned> g_next[MAXDEV];
+int* next_set() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAXDEV) return nullptr;
+    int* b = g_base[dev].load(std::memory_order_acquire);
+    return b ? b + SET_INTS * (g_next[dev].fetch_add(1u, std::memory_order_relaxed) % SETS) : nullptr;
+}
+}  // namespace yume_counters
+
+extern "C" int64_t yume_counter_workspace_bytes(void) { return (int64_t)yume_counters::SETS * yume_counters::SET_INTS * (int64_t)sizeof(int); }
+
+extern "C" int yume_counter_workspace_init(void* ptr, int64_t bytes, void* stream) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= yume_counters::MAXDEV) {
+        yume_set_error("counter_workspace_init: no current device");
+        return YUME_ELAUNCH;
+    }
+    if (ptr == nullptr) {                                   // unregister: ticketed launches fall back to their static schedules
+        yume_counters::g_base[dev].store(nullptr, std::memory_order_release);
+        return YUME_OK;
+    }
+    YUME_REQUIRE(bytes >= yume_counter_workspace_bytes(), "counter_workspace_init: %lld bytes given, %lld needed", (long long)bytes,
+                 (long long)yume_counter_workspace_bytes());
+    YUME_REQUIRE((reinterpret_cast<uintptr_t>(ptr) & 63) == 0, "counter_workspace_init: the buffer must be 64-byte aligned");
+    if (hipMemsetAsync(ptr, 0, (size_t)yume_counter_workspace_bytes(), static_cast<hipStream_t>(stream)) != hipSuccess) {
+        yume_set_error("counter_workspace_init: memset failed");
+        return YUME_ELAUNCH;
+    }
+    yume_counters::g_base[dev].store(static_cast<int*>(ptr), std::memory_order_release);
+    return YUME_OK;
+}
 
 namespace {
 

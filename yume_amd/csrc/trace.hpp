@@ -6,6 +6,10 @@
 #ifdef YUME_TRACE
 #include <hip/hip_runtime.h>
 #define YUME_TRACE_MAX 32768
+// SINGLE-TRANSLATION-UNIT by contract: the buffer and its reader are defined HERE, so exactly one .hip file of a library may be compiled
+// with -DYUME_TRACE (tools/build_variant.sh rebuilds one file per variant and takes every other object from the product build). A second
+// traced file fails at link time on the duplicate yume_debug_trace_read symbol — deliberately: each unit would otherwise get its own
+// buffer and the reader would return only one of them.
 __device__ unsigned long long g_yume_trace[YUME_TRACE_MAX * 8];
 __device__ __forceinline__ void trace_stamp(int slot) {
     if (threadIdx.x == 0 && blockIdx.x < YUME_TRACE_MAX) {

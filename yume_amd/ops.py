@@ -35,6 +35,25 @@ def _ptr(t):
     return t.data_ptr() if t is not None else None
 
 
+_counters = {}
+
+
+def ensure_counters(device):
+    """Register (once per device) the caller-owned ticket-counter workspace of include/yume_hip.h (yume_counter_workspace_init): kernels
+    that hand out work by ticket — long convolutions' tails, the persistent attention kernel — draw their counters from it; the library
+    itself allocates nothing. The tensor lives for the life of the process."""
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    t = _counters.get(idx)
+    if t is None:
+        lib = _lib.load()
+        n = int(lib.yume_counter_workspace_bytes())
+        with torch.cuda.device(idx):
+            t = torch.zeros(n // 4, dtype=torch.int32, device=torch.device("cuda", idx))
+            _lib.check(lib.yume_counter_workspace_init(t.data_ptr(), n, _stream()), "yume_counter_workspace_init")
+        _counters[idx] = t
+    return t
+
+
 def adaln_modulate(x, mul, add, tab_stride, row_idx, add_one, out, out_kind=0, eps=1e-6):
     """out = LN(x) * (mul[row] + add_one) + add[row]; x fp32 [T,C]; mul/add fp32 table views (first row)."""
     lib = _lib.load()
@@ -142,6 +161,7 @@ def attn_fwd(q, k, vt, out, Lq, Lk, H, scale=None, accumulate=False, variant=0, 
     _dev(k, "k", torch.bfloat16)
     _dev(vt, "vt", torch.bfloat16)
     _dev(out, "out", torch.bfloat16)
+    ensure_counters(q.device)
     qp, ldq = _rows(q, "q")
     kp, ldk = _rows(k, "k")
     vp, ldv = _rows(vt, "vt")

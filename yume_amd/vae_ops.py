@@ -3,7 +3,7 @@ Activations are bf16 channels-last tensors [T, H, W, C] (contiguous, C % 8 == 0)
 import torch
 
 from . import _lib
-from .ops import _dev, _ptr, _stream
+from .ops import _dev, _ptr, _stream, ensure_counters
 
 EPI_BF16, EPI_F32, EPI_ADD, EPI_TSPLIT = 0, 2, 16, 17
 
@@ -20,6 +20,7 @@ def conv3d_cl(x, cache, w, bias, cout, k, stride, pad, ups, out, epi=EPI_BF16, a
     lib = _lib.load()
     _cl(x, "x")
     _cl(out, "out")
+    ensure_counters(x.device)
     Tin, Hin, Win, C = x.shape
     To, Ho, Wo, Cl = out.shape
     if epi == EPI_TSPLIT:
