@@ -147,7 +147,8 @@ int yume_rmsnorm_rows_periodic(void* buf, int64_t ld, int64_t T, int64_t C, cons
  *    wan/modules/model.py:379-387) using the fp32 accumulator before rounding.
  * variant: 0 = automatic (Lk >= 1536 and Lq >= 256: the one-wave-per-SIMD kernel, 256 queries per workgroup; otherwise
  *    the 4-wave LDS-DMA kernel), 1 = 4-wave register-staged kernel, 2 = 4-wave LDS-DMA kernel, 4 = 8-wave ping-pong
- *    kernel, 7 = one-wave-per-SIMD kernel (attn_fwd7.hip). All compute the same function (tests compare them).
+ *    kernel, 7 = one-wave-per-SIMD kernel (attn_fwd7.hip), 8 = its persistent form (attn_fwd8.hip; needs the two flags below). All
+ *    compute the same function (tests compare them).
  *    | YUME_ATTN_Q_PRESCALED: Q already carries scale * log2(e) — the caller folded that factor into the producer of Q before
  *    its one bf16 rounding (the DiT engine multiplies it into the RMSNorm weight of q, so yume_rmsnorm_rope writes it) — and
  *    `scale` is ignored:  O = sum_j 2^<Q,K_j> V_j / sum_j 2^<Q,K_j>.  The scores then leave the matrix pipe as the exponents
@@ -157,6 +158,14 @@ int yume_rmsnorm_rows_periodic(void* buf, int64_t ld, int64_t T, int64_t C, cons
  *    domain) is rerun in the same launch on the kernel's rescaling path, so the result is defined for every input.
  */
 #define YUME_ATTN_Q_PRESCALED 0x100
+/*    | YUME_ATTN_KV_PADDED: the caller guarantees that K has at least ceil(Lk/64)*64 readable rows (whatever they hold) and that Vt has
+ *    ldvt >= ceil(Lk/64)*64 with FINITE values in the columns >= Lk (they are multiplied by exact zeros). Together with
+ *    YUME_ATTN_Q_PRESCALED, Lk >= 512, Lq >= 256 and a registered counter workspace this lets variant 0 take the persistent kernel
+ *    (attn_fwd8.hip: one resident workgroup per CU draws (head, query block) items by ticket and streams K / V^T tiles continuously
+ *    across them — the ragged last key tile is fetched like any other and only masked); variant 8 insists on that kernel. Same
+ *    arithmetic per key tile in the same order as variant 7: whole query blocks are bit-identical. env YUME_ATTN_V8=0 keeps variant 0
+ *    off it (A/B runs). */
+#define YUME_ATTN_KV_PADDED 0x200
 int yume_attn_fwd(const void* Q, int64_t ldq, const void* K, int64_t ldk, const void* Vt, int64_t ldvt,
                   void* O, int64_t ldo, int64_t Lq, int64_t Lk, int64_t H, float scale,
                   int accumulate, int variant, void* stream);

@@ -1,7 +1,9 @@
 // attn_check — standalone (no torch) correctness + timing harness for yume_attn_fwd variants.
 //   build:  hipcc -O2 --offload-arch=gfx950 tools/attn_check.cpp -o tools/attn_check -ldl      (NOT linked against the library: a second copy loaded first would capture the --lib build's calls)
-//   run:    tools/attn_check [variants...]        (default variants: 7 263 256 4 2 0; v + 256 = v | YUME_ATTN_Q_PRESCALED: the harness
-//           hands the kernel q' = bf16(q * scale * log2 e) and the references take exp2(q' . k))
+//   run:    tools/attn_check [variants...]        (default variants: 7 263 256 776 768 4 2 0; v + 256 = v | YUME_ATTN_Q_PRESCALED: the harness
+//           hands the kernel q' = bf16(q * scale * log2 e) and the references take exp2(q' . k); v + 512 = v | YUME_ATTN_KV_PADDED: the
+//           harness hands it K / V^T buffers padded to whole 64-key tiles — NaN rows behind K, finite junk behind V^T's columns; 776 =
+//           8 | 256 | 512 is the persistent kernel, which is also held BIT-IDENTICAL to variant 263 on launches without scratch)
 // Small shapes are checked against an fp64 exact-softmax reference computed on the host (test infrastructure, like oracle/);
 // large shapes are checked against variant 2 (itself checked on the small shapes) and timed with HIP events.
 #include <hip/hip_runtime.h>
@@ -18,6 +20,8 @@
 typedef int (*attn_fn)(const void*, int64_t, const void*, int64_t, const void*, int64_t, void*, int64_t, int64_t, int64_t, int64_t, float, int, int, void*, int64_t, void*);
 typedef int64_t (*ws_fn)(int64_t, int64_t, int64_t);
 typedef const char* (*err_fn)();
+typedef int64_t (*cwb_fn)();
+typedef int (*cwi_fn)(void*, int64_t, void*);
 static attn_fn p_attn; static ws_fn p_ws; static err_fn p_err;
 #define yume_attn_fwd_ws p_attn
 #define yume_attn_workspace_bytes p_ws
@@ -45,6 +49,7 @@ struct Prob {
     int64_t Lq, Lk, H, ldq, ldk, ldvt, ldo;
     std::vector<uint16_t> q, qpre, k, vt, o0;
     uint16_t *dq, *dqpre, *dk, *dvt, *d_o;
+    uint16_t *dkp, *dvtp; int64_t ldvtp;      // YUME_ATTN_KV_PADDED images: K with NaN rows up to a whole tile, V^T with finite junk columns
     void* ws; int64_t wsb;
 };
 
@@ -89,16 +94,28 @@ static void make(Prob& p, int64_t Lq, int64_t Lk, int64_t H, int spike) {
     HC(hipMemcpy(p.dq, p.q.data(), p.q.size() * 2, hipMemcpyHostToDevice));
     HC(hipMemcpy(p.dk, p.k.data(), p.k.size() * 2, hipMemcpyHostToDevice));
     HC(hipMemcpy(p.dvt, p.vt.data(), p.vt.size() * 2, hipMemcpyHostToDevice));
+    {
+        const int64_t nk = (Lk + 63) / 64 * 64;
+        p.ldvtp = nk;
+        std::vector<uint16_t> kp(nk * p.ldk, 0x7fc0), vp(H * 128 * nk);
+        memcpy(kp.data(), p.k.data(), p.k.size() * 2);
+        for (int64_t r = 0; r < H * 128; ++r)
+            for (int64_t c = 0; c < nk; ++c) vp[r * nk + c] = c < Lk ? p.vt[r * p.ldvt + c] : f2bf(100.0f * rnd());
+        HC(hipMalloc(&p.dkp, kp.size() * 2)); HC(hipMalloc(&p.dvtp, vp.size() * 2));
+        HC(hipMemcpy(p.dkp, kp.data(), kp.size() * 2, hipMemcpyHostToDevice));
+        HC(hipMemcpy(p.dvtp, vp.data(), vp.size() * 2, hipMemcpyHostToDevice));
+    }
     p.wsb = yume_attn_workspace_bytes(Lq, Lk, H);
     p.ws = nullptr;
     if (p.wsb) HC(hipMalloc(&p.ws, p.wsb));
 }
-static void drop(Prob& p) { hipFree(p.dqpre); hipFree(p.dq); hipFree(p.dk); hipFree(p.dvt); hipFree(p.d_o); if (p.ws) hipFree(p.ws); }
+static void drop(Prob& p) { hipFree(p.dqpre); hipFree(p.dq); hipFree(p.dk); hipFree(p.dvt); hipFree(p.d_o); hipFree(p.dkp); hipFree(p.dvtp); if (p.ws) hipFree(p.ws); }
 
-static int run(Prob& p, int variant, int accumulate, std::vector<uint16_t>& out) {
+static int run(Prob& p, int variant, int accumulate, std::vector<uint16_t>& out, bool scratch = true) {
     HC(hipMemcpy(p.d_o, p.o0.data(), p.o0.size() * 2, hipMemcpyHostToDevice));
-    int rc = yume_attn_fwd_ws((variant & 256) ? p.dqpre : p.dq, p.ldq, p.dk, p.ldk, p.dvt, p.ldvt, p.d_o, p.ldo, p.Lq, p.Lk, p.H, 0.08838834764831845f, accumulate, variant,
-                              p.ws, p.wsb, nullptr);
+    const bool pad = (variant & 512) != 0;
+    int rc = yume_attn_fwd_ws((variant & 256) ? p.dqpre : p.dq, p.ldq, pad ? p.dkp : p.dk, p.ldk, pad ? p.dvtp : p.dvt, pad ? p.ldvtp : p.ldvt, p.d_o, p.ldo, p.Lq, p.Lk,
+                              p.H, 0.08838834764831845f, accumulate, variant, scratch ? p.ws : nullptr, scratch ? p.wsb : 0, nullptr);
     if (rc) { printf("  variant %d: rc=%d %s\n", variant, rc, yume_last_error()); return rc; }
     hipError_t e = hipDeviceSynchronize();
     if (e != hipSuccess) { printf("  variant %d: device error %s\n", variant, hipGetErrorString(e)); exit(3); }
@@ -143,6 +160,24 @@ static double maxdiff(const std::vector<uint16_t>& a, const std::vector<float>& 
     }
     return m;
 }
+// where two outputs differ: how many values, in how many (query block, head) cells, the first few places — enough to tell a wrong item
+// boundary from a wrong tile or a wrong mask
+static size_t where_differs(const Prob& p, const std::vector<uint16_t>& a, const std::vector<uint16_t>& b) {
+    size_t nd = 0, cells = 0;
+    std::vector<char> cell(((p.Lq + 255) / 256) * p.H, 0);
+    for (int64_t i = 0; i < p.Lq; ++i)
+        for (int64_t c = 0; c < p.H * 128; ++c) {
+            const size_t ix = i * p.ldo + c;
+            if (a[ix] == b[ix]) continue;
+            if (nd < 6) printf("      row %lld (block %lld, wave %lld, lane-row %lld) head %lld d %lld: %g vs %g\n", (long long)i, (long long)(i / 256), (long long)((i % 256) / 64),
+                               (long long)(i % 64), (long long)(c / 128), (long long)(c % 128), bf2f(a[ix]), bf2f(b[ix]));
+            ++nd;
+            char& f = cell[(i / 256) * p.H + c / 128];
+            if (!f) { f = 1; ++cells; }
+        }
+    if (nd) printf("      %zu values differ in %zu of %zu (block, head) cells\n", nd, cells, cell.size());
+    return nd;
+}
 static double maxdiff2(const std::vector<uint16_t>& a, const std::vector<uint16_t>& b, int* nan) {
     double m = 0; *nan = 0;
     for (size_t i = 0; i < a.size(); ++i) {
@@ -173,12 +208,22 @@ int main(int argc, char** argv) {
     if (!hnd) { printf("dlopen %s: %s\n", lib, dlerror()); return 2; }
     p_attn = (attn_fn)dlsym(hnd, "yume_attn_fwd_ws"); p_ws = (ws_fn)dlsym(hnd, "yume_attn_workspace_bytes"); p_err = (err_fn)dlsym(hnd, "yume_last_error");
     printf("library %s\n", lib);
-    if (variants.empty()) variants = {7, 263, 256, 4, 2, 0};
+    {   // the caller-owned ticket-counter workspace (include/yume_hip.h): the persistent attention kernel draws its items from it
+        cwb_fn cwb = (cwb_fn)dlsym(hnd, "yume_counter_workspace_bytes");
+        cwi_fn cwi = (cwi_fn)dlsym(hnd, "yume_counter_workspace_init");
+        if (cwb && cwi) {
+            void* cw = nullptr;
+            HC(hipMalloc(&cw, cwb()));
+            if (cwi(cw, cwb(), nullptr)) { printf("counter workspace: %s\n", yume_last_error()); return 2; }
+            HC(hipDeviceSynchronize());
+        }
+    }
+    if (variants.empty()) variants = {7, 263, 256, 776, 768, 4, 2, 0};
     int fails = 0;
     const int small[][4] = {{256, 64, 1, 0}, {64, 40, 1, 0}, {1, 1, 1, 0}, {300, 200, 2, 0}, {273, 323, 3, 0}, {256, 256, 1, 0}, {256, 320, 1, 0},
                             {513, 640, 9, 0}, {700, 1000, 8, 1}, {256, 577, 2, 1}, {260, 448, 1, 0}, {512, 512, 3, 1}, {384, 1999, 2, 1},
                             {700, 2100, 8, 1}, {1000, 3333, 16, 1}, {300, 1536, 1, 0}, {300, 1600, 2, 2}, {700, 2100, 8, 2}, {512, 4096, 3, 2},
-                            {256, 64, 1, 2}, {1100, 1984, 8, 0}};
+                            {256, 64, 1, 2}, {1100, 1984, 8, 0}, {2000, 512, 3, 0}, {1300, 515, 9, 1}, {4000, 2500, 12, 2}, {9000, 300, 2, 0}};
     for (auto& sh : small) {
         if (timing_only) break;
         for (int acc = 0; acc < 2; ++acc) {
@@ -189,8 +234,17 @@ int main(int argc, char** argv) {
             if (anypre) reference(p, acc, refpre, true);
             for (int v : variants) {
                 if ((v == 4) && (sh[0] < 1)) continue;
+                if ((v & 255) == 8 && (sh[0] < 256 || sh[1] < 512)) continue;          // outside the persistent kernel's shapes (it says so: checked below)
                 std::vector<uint16_t> out;
                 if (run(p, v, acc, out)) { ++fails; continue; }
+                if ((v & 255) == 8) {       // without scratch (whole query blocks only) the persistent kernel and variant 7 must agree bit for bit
+                    std::vector<uint16_t> a8, a7;
+                    if (run(p, v, acc, a8, false) || run(p, 7 | 256, acc, a7, false)) { ++fails; continue; }
+                    const size_t nd = where_differs(p, a8, a7);
+                    printf("small Lq=%d Lk=%d H=%d spike=%d acc=%d variant=%d  vs variant 263 without scratch: %zu differing values %s\n", sh[0], sh[1], sh[2], sh[3], acc, v, nd,
+                           nd ? "FAIL" : "ok");
+                    if (nd) ++fails;
+                }
                 int nan; double md = maxdiff(out, (v & 256) ? refpre : ref, &nan);
                 const bool ok = nan == 0 && md < (acc ? 6e-2 : 4e-2);
                 printf("small Lq=%d Lk=%d H=%d spike=%d acc=%d variant=%d  maxabs=%.3e nan=%d %s\n", sh[0], sh[1], sh[2], sh[3], acc, v, md, nan, ok ? "ok" : "FAIL");
@@ -242,6 +296,13 @@ int main(int argc, char** argv) {
             const bool ok = timing_only || (nan == 0 && md < 3e-2);
             printf("big Lq=%d Lk=%d H=%d variant=%d  vs v2 maxabs=%.3e nan=%d %s   %.3f ms  %.0f TFLOP/s\n", sh[0], sh[1], sh[2], v, md, nan, ok ? "ok" : "FAIL", ms, tf);
             if (!ok) ++fails;
+            if ((v & 255) == 8 && !timing_only) {
+                std::vector<uint16_t> a8, a7;
+                if (run(p, v, 0, a8, false) || run(p, 7 | 256, 0, a7, false)) { ++fails; continue; }
+                const size_t nd = where_differs(p, a8, a7);
+                printf("big Lq=%d Lk=%d H=%d variant=%d  vs variant 263 without scratch: %zu differing values %s\n", sh[0], sh[1], sh[2], v, nd, nd ? "FAIL" : "ok");
+                if (nd) ++fails;
+            }
         }
         drop(p);
     }

@@ -22,6 +22,7 @@
 // Roofline: MFMA (bf16 dense). Algorithmic work 4*Lq*Lk*128 flop per head.
 #include "common.hpp"
 #include "attn_args.hpp"
+#include "counters.hpp"
 #include "trace.hpp"
 
 namespace {
@@ -1019,12 +1020,87 @@ static Plan7 attn7_plan_search(int64_t Lq, int64_t Lk, int64_t H) {
 }
 static bool attn7_applies(int64_t Lq, int64_t Lk) { return Lk >= 1536 && Lq >= QB4; }
 
+// ---- launch plan of the persistent kernel (attn_fwd8.hip) ------------------------------------------------------------------
+// The same item list as attn_fwd7's (whole query blocks, then the key-range pieces of the last `nq - tail_qb` blocks of every head), drawn
+// by ticket instead of dispatched in block-id order. An item boundary costs ~2.5 tile times there (two bubbles) instead of a whole prologue
+// and epilogue, so shorter pieces pay: down to 4 key tiles (the 512-key cross-attention: 8 tiles per block, halves of 4).
+static Plan7 attn8_plan_search(int64_t Lq, int64_t Lk, int64_t H) {
+    const int64_t nq = (Lq + QB4 - 1) / QB4, hx = (H + 7) / 8, nt = (Lk + KT - 1) / KT;
+    Plan7 best{nq, 1};
+    const double bub = 2.5, whole = (double)nt + bub;
+    auto makespan = [&](int64_t tail_q, int splits) {
+        double cu[32];
+        for (double& c : cu) c = 0.0;
+        auto put = [&](double cost) {
+            int m = 0;
+            for (int i = 1; i < 32; ++i) if (cu[i] < cu[m]) m = i;
+            cu[m] += cost;
+        };
+        for (int64_t i = 0; i < hx * (nq - tail_q); ++i) put(whole);
+        for (int64_t i = 0; i < hx * tail_q * splits; ++i) put((double)nt / splits + bub + 1.0);        // + the fp32 partial store
+        double mx = 0.0;
+        for (double c : cu) mx = c > mx ? c : mx;
+        return mx + (splits > 1 ? 6.0 : 0.0);       // + the merge pass
+    };
+    double bm = makespan(0, 1);
+    for (int splits = 2; splits <= 4; ++splits) {
+        if (nt / splits < 4) break;
+        for (int64_t tail_q = 1; tail_q <= nq && tail_q <= 12; ++tail_q) {
+            const double m = makespan(tail_q, splits);
+            if (m < bm - 0.01 * whole) { bm = m; best = Plan7{nq - tail_q, splits}; }
+        }
+    }
+    return best;
+}
+static Plan7 attn8_plan(int64_t Lq, int64_t Lk, int64_t H) {
+    struct Entry { int64_t Lq, Lk, H; Plan7 pl; };
+    static thread_local Entry memo[8];
+    static thread_local int used = 0, next = 0;
+    for (int i = 0; i < used; ++i)
+        if (memo[i].Lq == Lq && memo[i].Lk == Lk && memo[i].H == H) return memo[i].pl;
+    const Plan7 pl = attn8_plan_search(Lq, Lk, H);
+    memo[next] = Entry{Lq, Lk, H, pl};
+    next = (next + 1) & 7;
+    used = used < 8 ? used + 1 : 8;
+    return pl;
+}
+// shapes the persistent kernel takes (the caller's flags and the counter workspace are checked at the call)
+static bool attn8_applies(int64_t Lq, int64_t Lk) { return Lk >= 8 * KT && Lq >= QB4; }
+static bool attn8_enabled() {
+    static const bool on = [] { const char* v = getenv("YUME_ATTN_V8"); return !v || atoi(v) != 0; }();
+    return on;
+}
+static int cu_count() {
+    static thread_local int n[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    if (!n[dev]) {
+        int v = 0;
+        n[dev] = (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256;
+    }
+    return n[dev];
+}
+
+static int64_t attn7_workspace(int64_t Lq, int64_t Lk, int64_t H);
+static int64_t attn8_workspace(int64_t Lq, int64_t Lk, int64_t H);
+// (the call does not know which flags the launches will carry: the larger of the two kernels' needs)
 extern "C" int64_t yume_attn_workspace_bytes(int64_t Lq, int64_t Lk, int64_t H) {
-    if (Lq <= 0 || Lk <= 0 || H <= 0 || !attn7_applies(Lq, Lk)) return 0;
+    if (Lq <= 0 || Lk <= 0 || H <= 0) return 0;
+    const int64_t a = attn7_workspace(Lq, Lk, H), b = attn8_workspace(Lq, Lk, H);
+    return a > b ? a : b;
+}
+static int64_t attn7_workspace(int64_t Lq, int64_t Lk, int64_t H) {
+    if (!attn7_applies(Lq, Lk)) return 0;
     const Plan7 pl = attn7_plan(Lq, Lk, H);
     if (pl.splits == 1) return 0;
     const int64_t rows = Lq - pl.tail_qb * QB4;
     return (int64_t)pl.splits * rows * (H * D + H * 2) * 4;
+}
+static int64_t attn8_workspace(int64_t Lq, int64_t Lk, int64_t H) {
+    if (!attn8_applies(Lq, Lk)) return 0;
+    const Plan7 pl = attn8_plan(Lq, Lk, H);
+    if (pl.splits == 1) return 0;
+    return (int64_t)pl.splits * (Lq - pl.tail_qb * QB4) * (H * D + H * 2) * 4;
 }
 
 extern "C" int yume_attn_fwd_ws(const void* Q, int64_t ldq, const void* K, int64_t ldk, const void* Vt, int64_t ldvt,
@@ -1055,8 +1131,8 @@ extern "C" int yume_attn_fwd_ws(const void* Q, int64_t ldq, const void* K, int64
     a.Lq = (int)Lq; a.Lk = (int)Lk; a.H = (int)H;
     // YUME_ATTN_Q_PRESCALED: Q already carries scale * log2(e) (the caller folded it into the producer of Q before its bf16 rounding): the
     // scores are the exponents. `scale` is ignored; every kernel sees scale_log2 = 1, the one-wave-per-SIMD kernel runs its base-free pieces.
-    const int q_pre = (variant & YUME_ATTN_Q_PRESCALED) != 0;
-    variant &= ~YUME_ATTN_Q_PRESCALED;
+    const int q_pre = (variant & YUME_ATTN_Q_PRESCALED) != 0, kv_pad = (variant & YUME_ATTN_KV_PADDED) != 0;
+    variant &= ~(YUME_ATTN_Q_PRESCALED | YUME_ATTN_KV_PADDED);
     a.q_prescaled = q_pre;
     a.scale_log2 = q_pre ? 1.0f : scale * 1.4426950408889634f;
     a.accumulate = accumulate;
@@ -1087,6 +1163,46 @@ extern "C" int yume_attn_fwd_ws(const void* Q, int64_t ldq, const void* K, int64
         else
             hipLaunchKernelGGL(attn_fwd_kernel_v2, grid, dim3(NW * 64), 0, st, b);
     };
+    // the persistent kernel (attn_fwd8.hip): base-free body only, K / V^T padded to whole key tiles (the caller's word: YUME_ATTN_KV_PADDED;
+    // ldvt can be checked), a registered counter workspace for its tickets. variant 8 insists on it, variant 0 takes it where it applies.
+    const int64_t nt8 = (Lk + KT - 1) / KT;
+    const bool v8_fits = q_pre && kv_pad && attn8_applies(Lq, Lk) && ldvt >= nt8 * KT;
+    if (variant == 8) {
+        YUME_REQUIRE(v8_fits, "attn_fwd: variant 8 needs YUME_ATTN_Q_PRESCALED | YUME_ATTN_KV_PADDED, Lk >= 512, Lq >= 256 and ldvt >= %lld",
+                     (long long)(nt8 * KT));
+    }
+    if (variant == 8 || (variant == 0 && v8_fits && attn8_enabled())) {
+        int* counters = yume_counters::next_set();
+        if (variant == 8) YUME_REQUIRE(counters != nullptr, "attn_fwd: variant 8 needs a registered counter workspace (yume_counter_workspace_init)");
+        if (counters) {
+            Plan7 pl = attn8_plan(Lq, Lk, H);
+            const int64_t rows = Lq - pl.tail_qb * QB4;
+            const int64_t need = pl.splits > 1 ? (int64_t)pl.splits * rows * (H * D + H * 2) * 4 : 0;
+            AttnArgs b = a;
+            b.nqb = (int)((Lq + QB4 - 1) / QB4);
+            if (pl.splits > 1 && workspace && workspace_bytes >= need) {
+                b.tail_qb = (int)pl.tail_qb;
+                b.splits = pl.splits;
+                b.part_o = reinterpret_cast<float*>(workspace);
+                b.part_ml = b.part_o + (int64_t)pl.splits * rows * H * D;
+            } else {
+                pl = Plan7{b.nqb, 1};              // no scratch: whole query blocks only
+                b.tail_qb = b.nqb;
+                b.splits = 1;
+            }
+            int64_t items = 0;
+            for (int y = 0; y < 8; ++y) items += ((H + 7 - y) >> 3) * (b.tail_qb + (int64_t)(b.nqb - b.tail_qb) * b.splits);
+            const int nwg = (int)(items < cu_count() ? items : cu_count());
+            yume_attn8_launch(b, counters, nwg, st);
+            if (b.splits > 1) {
+                const int64_t nq = rows * H * (D / 4);
+                hipLaunchKernelGGL(attn_combine_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, st, b.part_o, b.part_ml, b.splits, rows,
+                                   (int)H, (unsigned short*)O, ldo, (int)(b.tail_qb * QB4), accumulate);
+            }
+            YUME_CHECK_LAUNCH("attn_fwd");
+            return YUME_OK;
+        }
+    }
     if (variant == 1 || variant == 2 || variant == 4 || variant == 7) {
         run(variant, 0, Lq);
     } else if (!attn7_applies(Lq, Lk)) {
