@@ -338,6 +338,19 @@ def bench_longvideo(args, rank, world, dev, built=None, emit=True):
     run(1, max(1, args.warmup))
     Ls.clear()
     hist, dt = _timed(lambda: run(args.chunks, args.steps), world)
+    # where a chunk's time goes (diagnostic pass behind the timed region, host clock with a synchronise between the parts)
+    parts = {}
+    if rank == 0:
+        def lap(name, fn):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            r = fn()
+            torch.cuda.synchronize()
+            parts[name] = (time.perf_counter() - t0) * 1e3
+            return r
+        h0 = lap("vae_encode_17_frames_ms", lambda: vae.encode([clip])[0])
+        h1, _ = lap("chunk0_denoise_ms", lambda: sampling.long_video_5b(model, None, h0, ctxs[0:1], args.steps, shift, lfz, generator=g, decode=False))
+        lap("chunk0_vae_decode_ms", lambda: vae.decode([h1[:, -lfz:]]))
     res = None
     if rank == 0:
         nsteps = args.chunks * args.steps
@@ -351,7 +364,7 @@ def bench_longvideo(args, rank, world, dev, built=None, emit=True):
                                      "tokens_per_chunk": Ls, "num_layers": cfg["num_layers"], "parallelism": f"dp{world} (independent videos, replicated weights)"},
                           "latents_per_s": world * args.chunks * lfz / dt, "final_history_latents": int(hist.shape[1]),
                           "weight_broadcast_collectives": n_bcast,
-                          "model_tflop_timed": tf, "model_tflops_per_gpu": tf / dt,
+                          "model_tflop_timed": tf, "model_tflops_per_gpu": tf / dt, "parts_of_one_chunk": parts,
                           "model_tflop_note": "DiT forwards of every chunk at its own L + 485.04 per chunk decode + 54.7 for the 17-frame encode"})
         if emit:
             print(json.dumps(res), flush=True)

@@ -51,7 +51,8 @@ def _start_step_job(name, which):
     import tempfile
     from oracle import step_job
     out = os.path.join(tempfile.gettempdir(), f"yume_step_{name}_{which}_{os.getpid()}.pt")
-    _STEP_JOBS[(name, which)] = (step_job.start_job(name, which, out), out)
+    # (64 threads for the 118.8 TFLOP 5B step, 32 for each of the two 14B forwards: 128 of the GPU box's 256 hardware threads)
+    _STEP_JOBS[(name, which)] = (step_job.start_job(name, which, out, threads=64 if name == "5b" else 32), out)
 
 
 def pytest_collection_finish(session):

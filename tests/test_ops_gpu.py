@@ -289,6 +289,95 @@ def test_attention_auto_splits_query_range_between_kernels():
     assert rel_l2(o_ws[8192:].float().cpu(), o_no[8192:].float().cpu()) < 4e-3      # two bf16 roundings of fp32 values that differ in the last bits
 
 
+# ---- the persistent kernel (attn_fwd8.hip): variant 8, YUME_ATTN_Q_PRESCALED | YUME_ATTN_KV_PADDED -----------------------------
+def run_attn_padded(q, k, v, accumulate=None, variant=8, use_workspace=True, k_pad=float("nan"), v_pad=37.5):
+    """q [Lq, H, 128] PRESCALED bf16; K handed over with rows up to a whole 64-key tile (k_pad: NaN — nobody may use them), V^T with that many
+    columns holding FINITE junk behind column Lk (the contract of YUME_ATTN_KV_PADDED)."""
+    Lq, H, D = q.shape
+    Lk = k.shape[0]
+    Lp = (Lk + 63) // 64 * 64
+    kp = torch.full((Lp, H * D), k_pad, dtype=torch.bfloat16, device=DEV)
+    kp[:Lk] = k.reshape(Lk, H * D).to(DEV)
+    vt = torch.full((H * D, Lp), v_pad, dtype=torch.bfloat16, device=DEV)
+    ops.transpose_bf16(v.reshape(Lk, H * D).to(DEV), vt)
+    out = torch.empty(Lq, H * D, dtype=torch.bfloat16, device=DEV) if accumulate is None else accumulate
+    ops.attn_fwd(q.reshape(Lq, H * D).to(DEV), kp[:Lk], vt, out, Lq, Lk, H, accumulate=accumulate is not None, variant=variant, q_prescaled=True,
+                 kv_padded=True, use_workspace=use_workspace)
+    return out.cpu().view(Lq, H, D)
+
+
+# shapes: whole tiles / ragged last tile; 8-tile items (the cross-attention length) and long ones; fewer heads than XCDs (idle queues are
+# stolen from), more than one head per XCD, a partial last query block, more items than CUs (streaming across items), exactly 4..7 tiles
+# in the last piece
+V8_SHAPES = [(256, 512, 1), (300, 515, 2), (1000, 640, 3), (2048, 2048, 8), (700, 2100, 8), (1100, 1984, 9), (4000, 2500, 12), (9460, 512, 24), (5000, 1000, 24),
+             (70000, 576, 1)]
+
+
+@pytest.mark.parametrize("Lq,Lk,H", V8_SHAPES)
+def test_attention_persistent_kernel_matches_exact_softmax_and_variant_7(Lq, Lk, H):
+    q, k, v = (rnd(L, H, 128, seed=s, dtype=torch.bfloat16) for L, s in ((Lq, 21), (Lk, 22), (Lk, 23)))
+    qp = _prescale(q)
+    got = run_attn_padded(qp, k, v)
+    assert torch.isfinite(got).all()
+    if Lq * Lk * H <= 4000 * 2500 * 12:
+        want = attn_ref(qp, k, v, math.log(2.0))
+        assert (got.double() - want).abs().max() <= 1.5e-2 * max(want.abs().max().item(), 1e-3)
+        assert rel_l2(got, want) < 6e-3
+    else:
+        ref = run_attn(qp, k, v, variant=2, q_prescaled=True)
+        assert rel_l2(got.float(), ref.float()) < 3e-3
+    # the same arithmetic per key tile in the same order as attn_fwd7: without scratch (whole query blocks only) the two agree bit for bit
+    a8 = run_attn_padded(qp, k, v, use_workspace=False)
+    a7 = run_attn(qp, k, v, variant=7, q_prescaled=True)
+    assert torch.equal(a8, a7)
+    # variant 0 with both flags takes the same kernel
+    assert torch.equal(run_attn_padded(qp, k, v, variant=0), got)
+
+
+def test_attention_persistent_kernel_accumulate_and_repeated_launches():
+    """accumulate (the 14B image cross-attention sum) and the counter workspace's invariant: 300 launches in a row (more than the 256 counter
+    sets: every set is reused) keep giving the same bits — a launch that left its tickets behind would starve or repeat items."""
+    Lq, Lk, H = 3000, 1100, 5
+    q, k, v = (rnd(L, H, 128, seed=s, dtype=torch.bfloat16) for L, s in ((Lq, 31), (Lk, 32), (Lk, 33)))
+    qp = _prescale(q)
+    base = rnd(Lq, H * 128, seed=34, dtype=torch.bfloat16)
+    got = run_attn_padded(qp, k, v, accumulate=base.to(DEV).clone())
+    want = attn_ref(qp, k, v, math.log(2.0)) + base.view(Lq, H, 128).double()
+    assert (got.double() - want).abs().max() <= 2e-2 * want.abs().max()
+    first = run_attn_padded(qp, k, v)
+    for _ in range(300):
+        again = run_attn_padded(qp, k, v)
+    assert torch.equal(again, first)
+    from yume_amd.ops import _counters
+    torch.cuda.synchronize()
+    assert int(_counters[torch.cuda.current_device()].abs().sum()) == 0          # every launch put its zeros back
+
+
+@pytest.mark.parametrize("Lq,Lk,H", [(700, 2100, 8), (4000, 1600, 3), (8500, 2100, 8)])
+def test_attention_persistent_kernel_out_of_range_items_rerun_on_the_robust_pieces(Lq, Lk, H):
+    """as test_attention_prescaled_q_out_of_range_rows_take_the_robust_pieces: the items whose range vote fails are redone cold on attn_fwd7's
+    rescaling pieces inside the launch and the stream restarts behind them."""
+    q, k, v = (rnd(L, H, 128, seed=s, dtype=torch.bfloat16) for L, s in ((Lq, 11), (Lk, 12), (Lk, 13)))
+    q, k = q.float(), k.float()
+    k[:, :, 0] = 8.0
+    q[Lq - 2, :, 0] = -400.0
+    k[5] = q[3] * 40
+    k[Lk - 9] = q[Lq // 2] * 6
+    q, k = q.to(torch.bfloat16), k.to(torch.bfloat16)
+    qp = _prescale(q)
+    want = attn_ref(qp, k, v, math.log(2.0))
+    got = run_attn_padded(qp, k, v)
+    assert torch.isfinite(got).all()
+    assert (got.double() - want).abs().max() <= 2e-2 * want.abs().max()
+    assert rel_l2(got, want) < 6e-3
+
+
+def test_attention_persistent_kernel_refuses_what_it_cannot_take():
+    q, k, v = (rnd(L, 2, 128, seed=s, dtype=torch.bfloat16) for L, s in ((300, 1), (300, 2), (300, 3)))
+    with pytest.raises(RuntimeError, match="variant 8"):
+        run_attn_padded(_prescale(q), k, v)                       # Lk < 512
+
+
 def test_flash_attention_seam():
     from yume_amd.attention import flash_attention
     B, Lq, Lk, H = 2, 150, 90, 3

@@ -126,7 +126,7 @@ class DiTEngine:
                 "bqkv": f32(torch.cat([sa.q.bias, sa.k.bias, sa.v.bias])),
                 "nqk": f32(torch.cat([sa.norm_q.weight.double() * qs, sa.norm_k.weight.double()])),
                 "wo": bf(sa.o.weight), "bo": f32(sa.o.bias),
-                "wq_c": bf(ca.q.weight), "bq_c": f32(ca.q.bias), "nq_c": f32(ca.norm_q.weight),
+                "wq_c": bf(ca.q.weight), "bq_c": f32(ca.q.bias), "nq_c": f32(ca.norm_q.weight.double() * qs),   # (cross q carries the scale too)
                 "wo_c": bf(ca.o.weight), "bo_c": f32(ca.o.bias),
                 "w1": bf(b.ffn[0].weight), "b1": f32(b.ffn[0].bias),
                 "w2": bf(b.ffn[2].weight), "b2": f32(b.ffn[2].bias),
@@ -163,10 +163,12 @@ class DiTEngine:
             self._packed_key = key
 
     # ------------------------------------------------------------------ workspaces / per-clip tables
-    def _buf(self, name, shape, dtype):
+    def _buf(self, name, shape, dtype, zero=False):
+        """a workspace tensor, kept across calls while its shape holds. zero: zero-filled when (re)allocated — for buffers whose padding
+        (rows / columns no kernel writes) has to stay finite."""
         t = self._ws.get(name)
         if t is None or tuple(t.shape) != tuple(shape) or t.dtype != dtype or t.device != self.dev:
-            t = torch.empty(shape, dtype=dtype, device=self.dev)
+            t = (torch.zeros if zero else torch.empty)(shape, dtype=dtype, device=self.dev)
             self._ws[name] = t
         return t
 
@@ -256,8 +258,11 @@ class DiTEngine:
         """K (RMS-normalised) and K-major V^T of all blocks for one conditioning stream: kc [nk, nb*C], vct [nb*C, nk8].
         Recomputed only when `fresh` (always, unless cache_context found the same conditioning tensors)."""
         C, nb = self.model.dim, len(self.P["blocks"])
-        kc = self._buf(f"kc_{tag}_{nk}", (nk, nb * C), torch.bfloat16)
-        vct = self._buf(f"vct_{tag}_{nk}", (nb * C, _round_up(nk, 8)), torch.bfloat16)
+        # rows / columns up to a whole number of 64-key tiles exist and hold zeros: the attention kernels may fetch the ragged last key tile
+        # like any other (YUME_ATTN_KV_PADDED); the GEMM below writes nk rows / columns only
+        nk64 = _round_up(nk, 64)
+        kc = self._buf(f"kc_{tag}_{nk}", (nk64, nb * C), torch.bfloat16, zero=True)[:nk]
+        vct = self._buf(f"vct_{tag}_{nk}", (nb * C, nk64), torch.bfloat16, zero=True)
         if fresh:
             ops.gemm_bf16(ctx_rows, wkv, bkv, kc, EPI_BF16_SPLITT, out_t=vct, n_split=nb * C, variant=self.gemm_variant)
             ops.rmsnorm_rows_periodic(kc.view(nk * nb, C), C, nk_w, self.model.eps)
@@ -271,10 +276,11 @@ class DiTEngine:
         bf16 (x_out - x_in) of the listed blocks, 'replay' adds the stored residual instead of running them."""
         m = self.model
         C, H, Fd, eps = m.dim, m.num_heads, m.ffn_dim, m.eps
-        Lp = _round_up(L, 8)
+        # q|k rows and V^T columns exist (zeros) up to a whole number of 64-key tiles: YUME_ATTN_KV_PADDED (see _cross_kv)
+        Lp = _round_up(L, 64)
         h = self._buf("h", (L, C), torch.bfloat16)
-        qk = self._buf("qk", (L, 2 * C), torch.bfloat16)
-        vt = self._buf("vt", (C, Lp), torch.bfloat16)
+        qk = self._buf("qk", (Lp, 2 * C), torch.bfloat16, zero=True)[:L]
+        vt = self._buf("vt", (C, Lp), torch.bfloat16, zero=True)
         att = self._buf("att", (L, C), torch.bfloat16)
         ff = self._buf("ff", (L, Fd), torch.bfloat16)
         ts = 6 * C  # table row stride
@@ -307,7 +313,7 @@ class DiTEngine:
                 ops.rmsnorm_rope(qk[n_rope:], C, 2, d["nqk"], eps, None)
             if self.sp is None:
                 T("attn_self", ops.attn_fwd, qk[:, :C], qk[:, C:], vt, att, L, n_keys if n_keys is not None else L, H, variant=self.attn_variant,
-                  q_prescaled=self.q_prescale)
+                  q_prescaled=self.q_prescale, kv_padded=True)
                 sa = att
             else:      # Ulysses: all tokens x this rank's heads, then back (2 collectives, yume_amd/ulysses.py)
                 qf, kf, vtf = self.sp.exchange_qkv(qk, vt, C)
@@ -322,9 +328,11 @@ class DiTEngine:
                 ops.cast_bf16(xs, L, h)
             T("gemm_cross_q", ops.gemm_bf16, h, d["wq_c"], d["bq_c"], qk[:, :C], EPI_BF16, variant=self.gemm_variant)
             T("rmsnorm_rope", ops.rmsnorm_rope, qk[:, :C], C, 1, d["nq_c"], eps)
-            T("attn_cross", ops.attn_fwd, qk[:, :C], kc_t[:, i * C:(i + 1) * C], vct_t[i * C:(i + 1) * C], att, L, ntxt, H, variant=self.attn_variant)
+            T("attn_cross", ops.attn_fwd, qk[:, :C], kc_t[:, i * C:(i + 1) * C], vct_t[i * C:(i + 1) * C], att, L, ntxt, H, variant=self.attn_variant,
+              q_prescaled=self.q_prescale, kv_padded=True)
             if n_img:
-                T("attn_cross", ops.attn_fwd, qk[:, :C], kc_i[:, i * C:(i + 1) * C], vct_i[i * C:(i + 1) * C], att, L, n_img, H, accumulate=True, variant=self.attn_variant)
+                T("attn_cross", ops.attn_fwd, qk[:, :C], kc_i[:, i * C:(i + 1) * C], vct_i[i * C:(i + 1) * C], att, L, n_img, H, accumulate=True,
+                  variant=self.attn_variant, q_prescaled=self.q_prescale, kv_padded=True)
             T("gemm_cross_o", ops.gemm_bf16, att, d["wo_c"], d["bo_c"], xs, EPI_RESID, variant=self.gemm_variant)
             # --- FFN
             T("adaln", ops.adaln_modulate, xs, scale_ff, shift_ff, ts, row_idx, True, h, 0, eps)

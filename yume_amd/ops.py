@@ -151,11 +151,14 @@ _attn_ws, _attn_ws_bytes = {}, {}
 
 
 ATTN_Q_PRESCALED = 0x100     # YUME_ATTN_Q_PRESCALED
+ATTN_KV_PADDED = 0x200       # YUME_ATTN_KV_PADDED
 
 
-def attn_fwd(q, k, vt, out, Lq, Lk, H, scale=None, accumulate=False, variant=0, use_workspace=True, q_prescaled=False):
+def attn_fwd(q, k, vt, out, Lq, Lk, H, scale=None, accumulate=False, variant=0, use_workspace=True, q_prescaled=False, kv_padded=False):
     """out[Lq, H*128] = softmax(q k^T * scale) v ; q,k token-major bf16 2-D views, vt K-major [H*128, >=Lk].
-    q_prescaled: q already carries scale * log2(e) (`scale` is ignored): out = sum_j 2^(q.k_j) v_j / sum_j 2^(q.k_j)."""
+    q_prescaled: q already carries scale * log2(e) (`scale` is ignored): out = sum_j 2^(q.k_j) v_j / sum_j 2^(q.k_j).
+    kv_padded: the caller guarantees that k's storage is readable up to ceil(Lk/64)*64 rows and that vt has that many columns with finite
+    values behind column Lk (YUME_ATTN_KV_PADDED): with q_prescaled it opens the persistent kernel (attn_fwd8.hip)."""
     lib = _lib.load()
     _dev(q, "q", torch.bfloat16)
     _dev(k, "k", torch.bfloat16)
@@ -169,7 +172,7 @@ def attn_fwd(q, k, vt, out, Lq, Lk, H, scale=None, accumulate=False, variant=0, 
     if scale is None:
         scale = 1.0 / math.sqrt(128.0)
     ws, nbytes = None, 0
-    if variant == 0 and use_workspace:
+    if variant in (0, 8) and use_workspace:
         key = (q.device.index, Lq, Lk, H)
         nbytes = _attn_ws_bytes.get(key)
         if nbytes is None:
@@ -180,7 +183,8 @@ def attn_fwd(q, k, vt, out, Lq, Lk, H, scale=None, accumulate=False, variant=0, 
             if ws is None or ws.numel() < nbytes:
                 ws = _attn_ws[wkey] = torch.empty(nbytes, dtype=torch.uint8, device=q.device)
     rc = lib.yume_attn_fwd_ws(qp, ldq, kp, ldk, vp, ldv, op, ldo, Lq, Lk, H, scale, 1 if accumulate else 0,
-                              variant | (ATTN_Q_PRESCALED if q_prescaled else 0), _ptr(ws), nbytes if ws is not None else 0, _stream())
+                              variant | (ATTN_Q_PRESCALED if q_prescaled else 0) | (ATTN_KV_PADDED if kv_padded else 0), _ptr(ws),
+                              nbytes if ws is not None else 0, _stream())
     _lib.check(rc, "yume_attn_fwd")
     return out
 
