@@ -287,9 +287,11 @@ int main(int argc, char** argv) {
             hipEvent_t e0, e1; HC(hipEventCreate(&e0)); HC(hipEventCreate(&e1));
             const int it = sh[0] > 20000 ? 3 : 10;
             const uint16_t* qd = (v & 256) ? p.dqpre : p.dq;
-            for (int i = 0; i < 2; ++i) yume_attn_fwd_ws(qd, p.ldq, p.dk, p.ldk, p.dvt, p.ldvt, p.d_o, p.ldo, p.Lq, p.Lk, p.H, 0.0883883f, 0, v, p.ws, p.wsb, nullptr);
+            const uint16_t *kd = (v & 512) ? p.dkp : p.dk, *vd = (v & 512) ? p.dvtp : p.dvt;
+            const int64_t ldv = (v & 512) ? p.ldvtp : p.ldvt;
+            for (int i = 0; i < 2; ++i) yume_attn_fwd_ws(qd, p.ldq, kd, p.ldk, vd, ldv, p.d_o, p.ldo, p.Lq, p.Lk, p.H, 0.0883883f, 0, v, p.ws, p.wsb, nullptr);
             HC(hipEventRecord(e0, nullptr));
-            for (int i = 0; i < it; ++i) yume_attn_fwd_ws(qd, p.ldq, p.dk, p.ldk, p.dvt, p.ldvt, p.d_o, p.ldo, p.Lq, p.Lk, p.H, 0.0883883f, 0, v, p.ws, p.wsb, nullptr);
+            for (int i = 0; i < it; ++i) yume_attn_fwd_ws(qd, p.ldq, kd, p.ldk, vd, ldv, p.d_o, p.ldo, p.Lq, p.Lk, p.H, 0.0883883f, 0, v, p.ws, p.wsb, nullptr);
             HC(hipEventRecord(e1, nullptr)); HC(hipEventSynchronize(e1));
             float ms; HC(hipEventElapsedTime(&ms, e0, e1)); ms /= it;
             const double tf = 4.0 * sh[0] * sh[1] * 128.0 * sh[2] / (ms * 1e-3) / 1e12;

@@ -235,6 +235,7 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_kernel_v8(AttnArgs p, int* cn
     const int ql = lane & 31;
     const int nt = (p.Lk + KT - 1) / KT;
     const int xcd = blockIdx.x & 7;
+    TRACE_STAMP(0);
 
     Ctx cx;
     cx.smem = smem;
@@ -320,6 +321,7 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_kernel_v8(AttnArgs p, int* cn
         // what it waits for is the last tile's 8 pieces (1.5 us old) and the epilogue's stores, which the next tile's counted wait would
         // wait for anyway.
         __builtin_amdgcn_s_waitcnt(0x0F70);             // vmcnt(0)
+        if (g > 0) TRACE_STAMP(2);
         // the stream leaves an item behind its last tile: on to the next item's first tile, or — nothing left — to a harmless re-fetch
         // of this item's first tile (the statements stay unconditional; nobody reads what they bring)
         auto k_wrap = [&]() {
@@ -381,7 +383,9 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_kernel_v8(AttnArgs p, int* cn
         }
         const int jl = (cur.t1 - 1) * KT;                // first key of the item's last tile
         // ---- the tile before the last ----
+        TRACE_STAMP(3);      // (experiment builds, trace.hpp; the stamps of a workgroup's LAST item boundary survive: tools/trace8.py)
         tile8_any<1>(g, cx, dp, kg, vg, kstep, A, B, ring, jl);
+        TRACE_STAMP(4);
         ++g;
         ++t;
         --kleft;
@@ -400,8 +404,10 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_kernel_v8(AttnArgs p, int* cn
             load_q_agpr<QB>(qbase, (unsigned)(((int64_t)qb2 * p.ldq + 8 * hi) * 2));
             if (tid == 0) __atomic_store_n(&mail[0], drawn, __ATOMIC_RELAXED);
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            TRACE_STAMP(5);
             // ---- the last tile, its score half already the next item's ----
             tile8_any<2>(g, cx, dp, kg, vg, kstep, A, B, ring, jl);
+            TRACE_STAMP(6);
             ++g;
             --kleft;
             --vleft;
@@ -424,6 +430,7 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_kernel_v8(AttnArgs p, int* cn
         const int all_ok = votes[0] & votes[1] & votes[2] & votes[3];
         const int nn = nxt.nsp ? __atomic_load_n(&mail[0], __ATOMIC_RELAXED) : -1;             // (published by the last tile's barrier)
         __syncthreads();
+        if (nxt.nsp) TRACE_STAMP(1);
         if (__builtin_expect(!__builtin_amdgcn_readfirstlane(all_ok), 0)) {
             // out of the base-free body's range: the whole item again, cold, on attn_fwd7's rescaling pieces (any pointers, any Lk); the
             // stream's prefetched tiles are lost, the next item starts cold
