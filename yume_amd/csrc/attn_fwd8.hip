@@ -91,6 +91,17 @@ __device__ __forceinline__ int draw_ticket(const AttnArgs& p, int* cnt, int xcd,
     return -1;
 }
 
+// the lane id, rebuilt in two instructions wherever it is needed (volatile: not hoisted, not kept)
+__device__ __forceinline__ unsigned fresh_lane() {
+    unsigned l;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+    return l;
+}
+// one LDS-DMA piece of 64 lanes x 4 bytes (glds16's little brother)
+__device__ __forceinline__ void glds4(const char* sbase, unsigned voff, unsigned lds_dst) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+}
+
 // Q^T fragments of a block's query rows straight into the AGPRs a[XQ .. XQ+31] (lane (q, hi) holds Q[q][16*ks + 8*hi .. +7] -> a[XQ + 4*ks ..]):
 // eight 16-byte loads per lane, SGPR base + per-lane 32-bit offset. Completion is the caller's s_waitcnt vmcnt.
 template <int XQ>
@@ -184,15 +195,18 @@ template <int TS, int KIND>
 __device__ __forceinline__ void tile8(const Ctx& cx, const Dma7& dp, const char*& kg, const char*& vg, int64_t kstep, Blk& A, Blk& B, u32x4 (&ring)[RD], int jl) {
     constexpr int vb = TS * SLOT, nkb = ((TS + 2) & 3) * SLOT;
     constexpr int dk = TS * SLOT, dv = VB + ((TS + 3) & 3) * SLOT;
-    if constexpr (KIND != 0) {
+    if constexpr (KIND != 0 && KIND != 3) {
         // whatever of the softmax state hipcc parked in scratch across the bubble comes back HERE, in front of the counted wait (a reload
         // inside the tile would wait for the tile's own LDS-DMA pieces)
         PIN_BLK(A);
         PIN_BLK(B);
     }
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    // KIND 3: the first tile behind an item boundary. Everything it reads was waited for in bubble 1 (vmcnt(0) in front of the boundary
+    // tile); in flight are the boundary tile's 8 pieces — and the O^T stores of the item just finished, which a counted wait would have
+    // to sit out (one counter for loads and stores). Only the barrier.
+    if constexpr (KIND != 3) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    if constexpr (KIND == 0) {
+    if constexpr (KIND == 0 || KIND == 3) {
         phase<true, OA, QA, OB, true, true, true, false, true, false, true, -1, dk, dv>(cx, A, B, ring, vb, 0, 0, dp, kg, vg);
         phase<true, OB, QB, OA, true, true, true, false, true, false, false, nkb>(cx, B, A, ring, vb, 0, 0, dp, kg, vg);
     } else if constexpr (KIND == 1) {
@@ -228,6 +242,7 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_kernel_v8(AttnArgs p, int* cn
     __shared__ __attribute__((aligned(16))) char smem[LDS7];
     __shared__ int votes[4];                           // the range vote of the four waves
     __shared__ int mail[2];                            // tickets drawn by thread 0, read by everybody behind a barrier
+    __shared__ __attribute__((aligned(16))) int junk[4 * 128];   // where the Q' touch (below) drops what it fetched: 2 pieces x 256 B per wave
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -275,6 +290,8 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_kernel_v8(AttnArgs p, int* cn
     int g = 0;                      // tiles computed since the last cold start: tile g lives in slot g & 3
     int t = 0;                      // key tile (of cur) the next tile step computes
     bool cold = true;
+    bool first = false;             // the next tile step is the first behind an item boundary of the stream (KIND 3)
+    const unsigned junk_lds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) int*)junk + wave * 512;
 
     for (;;) {
         const char* const kb_cur = reinterpret_cast<const char*>(p.K + cur.h * D);
@@ -313,15 +330,13 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_kernel_v8(AttnArgs p, int* cn
             vg = vb_cur + (int64_t)(cur.t0 + 3) * (KT * 2);
             kleft = n - 4;
             vleft = n - 3;
+            // Everything hipcc itself has in flight ends HERE: the spill reloads on the edges that lead to a cold start (the first item, the
+            // robust rerun). hipcc cannot count the LDS-DMA pieces, so a load of its own that is still pending when a tile first touches
+            // the register costs an s_waitcnt vmcnt(0) INSIDE the tile (inside the steady loop, in the first build: one drain of the LDS-DMA
+            // queue per trip). The builtin, unlike an asm statement, clears hipcc's scoreboard.
+            __builtin_amdgcn_s_waitcnt(0x0F70);         // vmcnt(0)
+            first = false;
         }
-        // Everything hipcc itself has in flight ends HERE: spill reloads on the edges that join this point (from the cold start, from the
-        // robust rerun), the O^T stores of the item just finished. hipcc cannot count the LDS-DMA pieces, so a load of its own that is
-        // still pending when a tile first touches the register costs an s_waitcnt vmcnt(0) INSIDE the tile — inside the steady loop, in the
-        // first build: one full drain of the LDS-DMA queue per trip. The builtin (unlike an asm statement) clears hipcc's own scoreboard;
-        // what it waits for is the last tile's 8 pieces (1.5 us old) and the epilogue's stores, which the next tile's counted wait would
-        // wait for anyway.
-        __builtin_amdgcn_s_waitcnt(0x0F70);             // vmcnt(0)
-        if (g > 0) TRACE_STAMP(2);
         // the stream leaves an item behind its last tile: on to the next item's first tile, or — nothing left — to a harmless re-fetch
         // of this item's first tile (the statements stay unconditional; nobody reads what they bring)
         auto k_wrap = [&]() {
@@ -344,6 +359,7 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_kernel_v8(AttnArgs p, int* cn
         };
         if (kleft == 0) k_wrap();
         if (vleft == 0) v_wrap();
+        if (g > 0) TRACE_STAMP(2);
         kg = uniform_ptr(kg);
         vg = uniform_ptr(vg);
         kleft = __builtin_amdgcn_readfirstlane(kleft);
@@ -353,7 +369,32 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_kernel_v8(AttnArgs p, int* cn
 
         // ---- all tiles of the item but its last two: steady code ----
         int rem = cur.t1 - t;
+        bool touched = false;
+        // Q' touch: the next item's query rows are pulled towards the L2 a few tiles before bubble 1 loads them into the AGPRs — one dword
+        // of each 128-byte half row per lane, by LDS-DMA into a junk area (no destination register that the late data could clobber). Two
+        // more pieces in the queue: the next counted wait is that much stricter, nothing else.
+        auto touch = [&]() {
+            touched = true;
+            const unsigned l = fresh_lane();       // (not the kernel's long-lived lane values: those sit in scratch by now, and their reload would wait)
+            const int qn = p.q_lo + nxt.qb * QB7 + wave * 64 + (int)(l & 31);
+            const char* qbase = reinterpret_cast<const char*>(p.Q + nxt.h * D);
+            const int qa = qn < p.Lq ? qn : p.Lq - 1, qb2 = qn + 32 < p.Lq ? qn + 32 : p.Lq - 1;
+            glds4(qbase, (unsigned)qa * (unsigned)(p.ldq * 2) + (l >> 5) * 128u, junk_lds);
+            glds4(qbase, (unsigned)qb2 * (unsigned)(p.ldq * 2) + (l >> 5) * 128u, junk_lds + 256);
+        };
+        if (first && rem > 2) {
+            first = false;
+            tile8_any<3>(g, cx, dp, kg, vg, kstep, A, B, ring, 0);
+            ++g;
+            ++t;
+            --rem;
+            --kleft;
+            --vleft;
+            if (kleft == 0) k_wrap();
+            if (vleft == 0) v_wrap();
+        }
         while (rem > 2) {
+            if (rem <= 5 && !touched && nxt.nsp) touch();
             if ((g & 3) == 1 && rem >= 6 && kleft >= 4 && vleft >= 4) {
                 // (as attn_fwd7: claims dead score registers so that a spill reload parked in them is waited for HERE, not inside the loop.
                 // Only s[0]: element [1][15] of the scores is still read by the softmax drain in the first gap of the next tile.)
@@ -381,6 +422,7 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_kernel_v8(AttnArgs p, int* cn
             if (kleft == 0) k_wrap();
             if (vleft == 0) v_wrap();
         }
+        if (!touched && nxt.nsp) touch();
         const int jl = (cur.t1 - 1) * KT;                // first key of the item's last tile
         // ---- the tile before the last ----
         TRACE_STAMP(3);      // (experiment builds, trace.hpp; the stamps of a workgroup's LAST item boundary survive: tools/trace8.py)
@@ -397,11 +439,12 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_kernel_v8(AttnArgs p, int* cn
             //      next is drawn under the same latency and published by the next tile's barrier ----
             int drawn = 0;
             if (tid == 0) drawn = draw_ticket(p, cnt, xcd, nwg);
-            const int qn = p.q_lo + nxt.qb * QB7 + wave * 64 + ql;
+            const unsigned l = fresh_lane();
+            const int qn = p.q_lo + nxt.qb * QB7 + wave * 64 + (int)(l & 31);
             const char* qbase = reinterpret_cast<const char*>(p.Q + nxt.h * D);
             const int qa = qn < p.Lq ? qn : p.Lq - 1, qb2 = qn + 32 < p.Lq ? qn + 32 : p.Lq - 1;
-            load_q_agpr<QA>(qbase, (unsigned)(((int64_t)qa * p.ldq + 8 * hi) * 2));
-            load_q_agpr<QB>(qbase, (unsigned)(((int64_t)qb2 * p.ldq + 8 * hi) * 2));
+            load_q_agpr<QA>(qbase, (unsigned)qa * (unsigned)(p.ldq * 2) + (l >> 5) * 16u);
+            load_q_agpr<QB>(qbase, (unsigned)qb2 * (unsigned)(p.ldq * 2) + (l >> 5) * 16u);
             if (tid == 0) __atomic_store_n(&mail[0], drawn, __ATOMIC_RELAXED);
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             TRACE_STAMP(5);
@@ -441,6 +484,11 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_kernel_v8(AttnArgs p, int* cn
             run_keys<false, true>(p, cx, dp, A, B, q0, ql, cur.h, hi, cur.t0, cur.t1, nt, tid);
             cold = true;
         }
+        // hipcc's own loads end HERE, in front of the O^T stores: the spill reloads of what it parked across the boundary tile, the rerun's.
+        // Behind the stores nothing of hipcc's may be pending when the next tile starts — it would wait for it with a count that also
+        // covers the stores (the builtin, unlike an asm statement, clears hipcc's scoreboard; what it waits for besides is the boundary
+        // tile's 8 pieces, 3 us old).
+        __builtin_amdgcn_s_waitcnt(0x0F70);             // vmcnt(0)
         if (cur.nsp > 1) {
             const int row0 = p.q_lo + p.tail_qb * QB7;
             const int64_t rows = p.Lq - row0;
@@ -460,6 +508,7 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_kernel_v8(AttnArgs p, int* cn
             A.z.l_run = 0.f;
             B.z.l_run = 0.f;
             NOP_PAD();                                   // accvgpr writes -> MFMA C operands
+            first = true;
         }
     }
 }
