@@ -27,5 +27,5 @@ struct AttnArgs {
 void yume_attn7_launch(const AttnArgs& a, hipStream_t st);
 // attn_fwd8.hip: the same kernel as `nwg` persistent workgroups over one continuous K / V^T stream; items (the query blocks of a.nqb /
 // a.tail_qb / a.splits, as for attn_fwd7) are drawn by ticket from `counters`, one 64-byte set of the caller's counter workspace
-// (counters.hpp). Requires a.q_prescaled, K readable and V^T finite up to a whole number of 64-key tiles, every item >= 4 key tiles.
+// (counters.hpp). Requires a.q_prescaled, K readable and V^T finite up to a whole number of 64-key tiles, every item >= 5 key tiles.
 void yume_attn8_launch(const AttnArgs& a, int* counters, int nwg, hipStream_t st);

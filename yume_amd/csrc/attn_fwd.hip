@@ -1023,7 +1023,7 @@ static bool attn7_applies(int64_t Lq, int64_t Lk) { return Lk >= 1536 && Lq >= Q
 // ---- launch plan of the persistent kernel (attn_fwd8.hip) ------------------------------------------------------------------
 // The same item list as attn_fwd7's (whole query blocks, then the key-range pieces of the last `nq - tail_qb` blocks of every head), drawn
 // by ticket instead of dispatched in block-id order. An item boundary costs ~2.5 tile times there (two bubbles) instead of a whole prologue
-// and epilogue, so shorter pieces pay: down to 4 key tiles (the 512-key cross-attention: 8 tiles per block, halves of 4).
+// and epilogue, so shorter pieces pay: down to 5 key tiles.
 static Plan7 attn8_plan_search(int64_t Lq, int64_t Lk, int64_t H) {
     const int64_t nq = (Lq + QB4 - 1) / QB4, hx = (H + 7) / 8, nt = (Lk + KT - 1) / KT;
     Plan7 best{nq, 1};
@@ -1044,7 +1044,7 @@ static Plan7 attn8_plan_search(int64_t Lq, int64_t Lk, int64_t H) {
     };
     double bm = makespan(0, 1);
     for (int splits = 2; splits <= 4; ++splits) {
-        if (nt / splits < 4) break;
+        if (nt / splits < 5) break;                  // (an item of the stream is at least 5 tiles: its successor's ticket is drawn while it runs)
         for (int64_t tail_q = 1; tail_q <= nq && tail_q <= 12; ++tail_q) {
             const double m = makespan(tail_q, splits);
             if (m < bm - 0.01 * whole) { bm = m; best = Plan7{nq - tail_q, splits}; }
@@ -1171,7 +1171,9 @@ extern "C" int yume_attn_fwd_ws(const void* Q, int64_t ldq, const void* K, int64
         YUME_REQUIRE(v8_fits, "attn_fwd: variant 8 needs YUME_ATTN_Q_PRESCALED | YUME_ATTN_KV_PADDED, Lk >= 512, Lq >= 256 and ldvt >= %lld",
                      (long long)(nt8 * KT));
     }
-    if (variant == 8 || (variant == 0 && v8_fits && attn8_enabled())) {
+    // (variant 0: where attn_fwd7 was the choice. Measured, the 512-key cross-attention — 8 tiles per item, an item boundary every 12 us —
+    // stays faster on the 4-wave kernel: 0.101 against 0.132 ms in the bench, profiles/r4_bench_ab_v8_on_off.log)
+    if (variant == 8 || (variant == 0 && v8_fits && attn7_applies(Lq, Lk) && attn8_enabled())) {
         int* counters = yume_counters::next_set();
         if (variant == 8) YUME_REQUIRE(counters != nullptr, "attn_fwd: variant 8 needs a registered counter workspace (yume_counter_workspace_init)");
         if (counters) {

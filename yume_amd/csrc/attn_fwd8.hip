@@ -270,17 +270,17 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_kernel_v8(AttnArgs p, int* cn
     const int64_t kstep = (int64_t)KT * dp.krow;
     const int64_t vhead = (int64_t)D * p.ldvt * 2;     // bytes between two heads' V^T rows
 
-    // ---- the first two tickets ----
-    if (tid == 0) {
-        const int a = draw_ticket(p, cnt, xcd, nwg);
-        __atomic_store_n(&mail[0], a, __ATOMIC_RELAXED);
-        __atomic_store_n(&mail[1], a >= 0 ? draw_ticket(p, cnt, xcd, nwg) : -1, __ATOMIC_RELAXED);
-    }
+    // ---- the first ticket. The NEXT item is always drawn late — about eight tiles before the stream needs its first K tile — not a
+    //      whole item ahead: a ticket held early is an item no idle CU can take (in the first build the tail of the 5B shape, 30 half
+    //      pieces per XCD reserved an item early by CUs that still had a whole block to finish, cost 6 %) ----
+    if (tid == 0) __atomic_store_n(&mail[0], draw_ticket(p, cnt, xcd, nwg), __ATOMIC_RELAXED);
     __syncthreads();
     Item cur = decode_item(p, __builtin_amdgcn_readfirstlane(__atomic_load_n(&mail[0], __ATOMIC_RELAXED)), nt);
-    Item nxt = decode_item(p, __builtin_amdgcn_readfirstlane(__atomic_load_n(&mail[1], __ATOMIC_RELAXED)), nt);
+    Item nxt = decode_item(p, -1, nt);
     __syncthreads();
     if (cur.nsp == 0) return;
+    bool have_nxt = false;          // nxt is decoded
+    bool drew = false;              // thread 0 has put a fresh ticket into the mailbox; the next tile's barrier publishes it
 
     Blk A, B;
     u32x4 ring[RD];
@@ -305,7 +305,7 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_kernel_v8(AttnArgs p, int* cn
             load_q<OA, QA, true, true>(p, A, q0 + ql, cur.h, hi);
             load_q<OB, QB, true, true>(p, B, q0 + 32 + ql, cur.h, hi);
             __builtin_amdgcn_sched_barrier(0);
-            const int n = cur.t1 - cur.t0;             // >= 4 (launcher)
+            const int n = cur.t1 - cur.t0;             // >= 5 (launcher)
             // K(t0) | K(t0+1) V(t0) | K(t0+2) V(t0+1) | K(t0+3) V(t0+2) -> slots 0, 1, 2, 3 / 0, 1, 2
             dma7_k(dp, p, cur.t0, false, cx.lds0, wave);
             dma7_k(dp, p, cur.t0 + 1, false, cx.lds0 + SLOT, wave);
@@ -337,39 +337,62 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_kernel_v8(AttnArgs p, int* cn
             __builtin_amdgcn_s_waitcnt(0x0F70);         // vmcnt(0)
             first = false;
         }
-        // the stream leaves an item behind its last tile: on to the next item's first tile, or — nothing left — to a harmless re-fetch
-        // of this item's first tile (the statements stay unconditional; nobody reads what they bring)
-        auto k_wrap = [&]() {
-            if (nxt.nsp) {
-                kg = reinterpret_cast<const char*>(p.K + nxt.h * D) + (int64_t)nxt.t0 * kstep;
-                kleft = nxt.t1 - nxt.t0;
-            } else {
-                kg = kb_cur + (int64_t)cur.t0 * kstep;
-                kleft = 1 << 28;
-            }
-        };
-        auto v_wrap = [&]() {
-            if (nxt.nsp) {
-                vg = reinterpret_cast<const char*>(p.Vt) + (int64_t)nxt.h * vhead + (int64_t)nxt.t0 * (KT * 2);
-                vleft = nxt.t1 - nxt.t0;
-            } else {
-                vg = vb_cur + (int64_t)cur.t0 * (KT * 2);
-                vleft = 1 << 28;
-            }
-        };
-        if (kleft == 0) k_wrap();
-        if (vleft == 0) v_wrap();
-        if (g > 0) TRACE_STAMP(2);
         kg = uniform_ptr(kg);
         vg = uniform_ptr(vg);
         kleft = __builtin_amdgcn_readfirstlane(kleft);
         vleft = __builtin_amdgcn_readfirstlane(vleft);
         g = __builtin_amdgcn_readfirstlane(g);
         t = __builtin_amdgcn_readfirstlane(t);
-
-        // ---- all tiles of the item but its last two: steady code ----
         int rem = cur.t1 - t;
         bool touched = false;
+
+        // the next item's ticket: drawn by thread 0 when at most 8 tiles of this item are left, read by everybody one tile (one barrier) later
+        auto next_ticket = [&]() {
+            if (have_nxt) return;
+            if (drew) {
+                nxt = decode_item(p, __builtin_amdgcn_readfirstlane(__atomic_load_n(&mail[0], __ATOMIC_RELAXED)), nt);
+                have_nxt = true;
+                drew = false;
+            } else if (rem <= 8) {
+                if (tid == 0) __atomic_store_n(&mail[0], draw_ticket(p, cnt, xcd, nwg), __ATOMIC_RELAXED);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                drew = true;
+            }
+        };
+        // (items are at least 5 tiles long, so the ticket is known before the stream wraps; should it ever not be — draw and publish now)
+        auto need_nxt = [&]() {
+            if (have_nxt) return;
+            if (!drew && tid == 0) __atomic_store_n(&mail[0], draw_ticket(p, cnt, xcd, nwg), __ATOMIC_RELAXED);
+            __syncthreads();
+            nxt = decode_item(p, __builtin_amdgcn_readfirstlane(__atomic_load_n(&mail[0], __ATOMIC_RELAXED)), nt);
+            __syncthreads();
+            have_nxt = true;
+            drew = false;
+        };
+        // the stream leaves an item behind its last tile: on to the next item's first tile, or — nothing left — to a harmless re-fetch
+        // of this item's first tile (the statements stay unconditional; nobody reads what they bring)
+        auto wraps = [&]() {
+            if (kleft == 0) {
+                need_nxt();
+                if (nxt.nsp) {
+                    kg = reinterpret_cast<const char*>(p.K + nxt.h * D) + (int64_t)nxt.t0 * kstep;
+                    kleft = nxt.t1 - nxt.t0;
+                } else {
+                    kg = kb_cur + (int64_t)cur.t0 * kstep;
+                    kleft = 1 << 28;
+                }
+            }
+            if (vleft == 0) {
+                need_nxt();
+                if (nxt.nsp) {
+                    vg = reinterpret_cast<const char*>(p.Vt) + (int64_t)nxt.h * vhead + (int64_t)nxt.t0 * (KT * 2);
+                    vleft = nxt.t1 - nxt.t0;
+                } else {
+                    vg = vb_cur + (int64_t)cur.t0 * (KT * 2);
+                    vleft = 1 << 28;
+                }
+            }
+        };
         // Q' touch: the next item's query rows are pulled towards the L2 a few tiles before bubble 1 loads them into the AGPRs — one dword
         // of each 128-byte half row per lane, by LDS-DMA into a junk area (no destination register that the late data could clobber). Two
         // more pieces in the queue: the next counted wait is that much stricter, nothing else.
@@ -382,20 +405,28 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_kernel_v8(AttnArgs p, int* cn
             glds4(qbase, (unsigned)qa * (unsigned)(p.ldq * 2) + (l >> 5) * 128u, junk_lds);
             glds4(qbase, (unsigned)qb2 * (unsigned)(p.ldq * 2) + (l >> 5) * 128u, junk_lds + 256);
         };
-        if (first && rem > 2) {
-            first = false;
-            tile8_any<3>(g, cx, dp, kg, vg, kstep, A, B, ring, 0);
+        auto stepped = [&]() {
             ++g;
             ++t;
             --rem;
             --kleft;
             --vleft;
-            if (kleft == 0) k_wrap();
-            if (vleft == 0) v_wrap();
+        };
+
+        next_ticket();
+        wraps();
+        if (g > 0) TRACE_STAMP(2);
+        // ---- all tiles of the item but its last two: steady code ----
+        if (first) {                                     // (n >= 5: rem > 2 here)
+            first = false;
+            tile8_any<3>(g, cx, dp, kg, vg, kstep, A, B, ring, 0);
+            stepped();
+            next_ticket();
+            wraps();
         }
         while (rem > 2) {
-            if (rem <= 5 && !touched && nxt.nsp) touch();
-            if ((g & 3) == 1 && rem >= 6 && kleft >= 4 && vleft >= 4) {
+            if (rem <= 5 && !touched && have_nxt && nxt.nsp) touch();
+            if ((g & 3) == 1 && rem >= 10 && kleft >= 4 && vleft >= 4) {
                 // (as attn_fwd7: claims dead score registers so that a spill reload parked in them is waited for HERE, not inside the loop.
                 // Only s[0]: element [1][15] of the scores is still read by the softmax drain in the first gap of the next tile.)
                 asm volatile("" : "=v"(A.s[0]));
@@ -410,43 +441,32 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_kernel_v8(AttnArgs p, int* cn
                     rem -= 4;
                     kleft -= 4;
                     vleft -= 4;
-                } while (rem >= 6 && kleft >= 4 && vleft >= 4);
+                } while (rem >= 10 && kleft >= 4 && vleft >= 4);      // (the trips end where the next ticket is due: rem <= 9)
             } else {
                 tile8_any<0>(g, cx, dp, kg, vg, kstep, A, B, ring, 0);
-                ++g;
-                ++t;
-                --rem;
-                --kleft;
-                --vleft;
+                stepped();
             }
-            if (kleft == 0) k_wrap();
-            if (vleft == 0) v_wrap();
+            next_ticket();
+            wraps();
         }
+        need_nxt();
         if (!touched && nxt.nsp) touch();
         const int jl = (cur.t1 - 1) * KT;                // first key of the item's last tile
         // ---- the tile before the last ----
         TRACE_STAMP(3);      // (experiment builds, trace.hpp; the stamps of a workgroup's LAST item boundary survive: tools/trace8.py)
         tile8_any<1>(g, cx, dp, kg, vg, kstep, A, B, ring, jl);
         TRACE_STAMP(4);
-        ++g;
-        ++t;
-        --kleft;
-        --vleft;
-        if (kleft == 0) k_wrap();
-        if (vleft == 0) v_wrap();
+        stepped();
+        wraps();
         if (nxt.nsp) {
-            // ---- bubble 1: Q' into the AGPRs Q has just left (its last use was S(last) in the tile above); the ticket for the item after
-            //      next is drawn under the same latency and published by the next tile's barrier ----
-            int drawn = 0;
-            if (tid == 0) drawn = draw_ticket(p, cnt, xcd, nwg);
+            // ---- bubble 1: Q' into the AGPRs Q has just left (its last use was S(last) in the tile above) ----
             const unsigned l = fresh_lane();
             const int qn = p.q_lo + nxt.qb * QB7 + wave * 64 + (int)(l & 31);
             const char* qbase = reinterpret_cast<const char*>(p.Q + nxt.h * D);
             const int qa = qn < p.Lq ? qn : p.Lq - 1, qb2 = qn + 32 < p.Lq ? qn + 32 : p.Lq - 1;
             load_q_agpr<QA>(qbase, (unsigned)qa * (unsigned)(p.ldq * 2) + (l >> 5) * 16u);
             load_q_agpr<QB>(qbase, (unsigned)qb2 * (unsigned)(p.ldq * 2) + (l >> 5) * 16u);
-            if (tid == 0) __atomic_store_n(&mail[0], drawn, __ATOMIC_RELAXED);
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             TRACE_STAMP(5);
             // ---- the last tile, its score half already the next item's ----
             tile8_any<2>(g, cx, dp, kg, vg, kstep, A, B, ring, jl);
@@ -471,7 +491,6 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_kernel_v8(AttnArgs p, int* cn
         if (lane == 0) votes[wave] = wave_ok;
         __syncthreads();
         const int all_ok = votes[0] & votes[1] & votes[2] & votes[3];
-        const int nn = nxt.nsp ? __atomic_load_n(&mail[0], __ATOMIC_RELAXED) : -1;             // (published by the last tile's barrier)
         __syncthreads();
         if (nxt.nsp) TRACE_STAMP(1);
         if (__builtin_expect(!__builtin_amdgcn_readfirstlane(all_ok), 0)) {
@@ -500,7 +519,8 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_kernel_v8(AttnArgs p, int* cn
         }
         if (nxt.nsp == 0) break;
         cur = nxt;
-        nxt = decode_item(p, __builtin_amdgcn_readfirstlane(nn), nt);
+        have_nxt = false;
+        drew = false;
         t = cur.t0;                                      // stream mode: S(t0) and half of its softmax exist already; the next tile step is "tile t0"
         if (!cold) {
             for_regs<OA, 64>([&](auto r) { agpr_set<decltype(r)::value>(0u); });
