@@ -46,8 +46,8 @@ def flops_fwd_5b(L, C=3072, ffn=14336, n=30, Lc=512, cin=48, cout=48):
 
 
 PMC_GROUP_FILE = "r3_pmc_gemm_block_shapes_v3.csv"      # tools/run_pmc_gemm.sh: ONE GEMM of the block per process -> one row set per group
-PMC_FILES = ("r3_pmc_traffic_v5.csv", "r2_pmc_traffic_v3.csv", "r2_pmc_dominant_kernels.csv", "r1_pmc_dominant_kernels.csv")
-PMC_KERNEL_OF_GROUP = {"attn_self": ("attn_fwd_kernel_v7", "attn_combine_kernel")}
+PMC_FILES = ("r4_pmc_traffic_attention_v8.csv", "r3_pmc_traffic_v5.csv", "r2_pmc_traffic_v3.csv", "r2_pmc_dominant_kernels.csv", "r1_pmc_dominant_kernels.csv")
+PMC_KERNEL_OF_GROUP = {"attn_self": ("attn_fwd_kernel_v8", "attn_combine_kernel"), "attn_cross": ("attn_fwd_kernel_v2",)}
 
 
 def pmc_traffic_bytes(group):
@@ -193,8 +193,8 @@ def kernel_rooflines(prof, steps, ms_per_step, L, cfg, Lc=512):
     C, Fd, H = cfg["dim"], cfg["ffn_dim"], cfg["num_heads"]
     D = C // H
     work = {   # group -> (bound, algorithmic flop or bytes per launch, description)
-        "attn_self": ("mfma", 4.0 * L * L * D * H, f"self-attention {L}x{L}x{H} heads, d={D}: attn_fwd_kernel_v7 (+ attn_combine_kernel for the "
-                      "query blocks of the partial last round, timed together as one yume_attn_fwd_ws call)"),
+        "attn_self": ("mfma", 4.0 * L * L * D * H, f"self-attention {L}x{L}x{H} heads, d={D}: attn_fwd_kernel_v8 (persistent workgroups, one continuous K/V^T "
+                      "stream; + attn_combine_kernel for the key-range pieces of the last query blocks, timed together as one yume_attn_fwd_ws call)"),
         "attn_cross": ("mfma", 4.0 * L * Lc * D * H, f"cross-attention {L}x{Lc}x{H} heads: attn_fwd_kernel_v2"),
         "gemm_qkv": ("mfma", 2.0 * L * 3 * C * C, f"QKV GEMM {L}x{3 * C}x{C}, transposed-V epilogue (gemm_w4_kernel + gemm128_kernel on the row remainder)"),
         "gemm_o": ("mfma", 2.0 * L * C * C, f"o-proj GEMM {L}x{C}x{C}, gate*y + residual epilogue"),

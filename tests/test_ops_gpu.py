@@ -330,8 +330,13 @@ def test_attention_persistent_kernel_matches_exact_softmax_and_variant_7(Lq, Lk,
     a8 = run_attn_padded(qp, k, v, use_workspace=False)
     a7 = run_attn(qp, k, v, variant=7, q_prescaled=True)
     assert torch.equal(a8, a7)
-    # variant 0 with both flags takes the same kernel
-    assert torch.equal(run_attn_padded(qp, k, v, variant=0), got)
+    # variant 0 with both flags takes the same kernel where attn_fwd7 was its choice (Lk >= 1536; shorter key sequences — the 512-key
+    # cross-attention — stay on the 4-wave kernel, which measured faster there)
+    auto = run_attn_padded(qp, k, v, variant=0)
+    if Lk >= 1536:
+        assert torch.equal(auto, got)
+    else:
+        assert rel_l2(auto.float(), got.float()) < 3e-3
 
 
 def test_attention_persistent_kernel_accumulate_and_repeated_launches():
