@@ -7,7 +7,7 @@ fill_module_hashed_, bit for bit; inputs from a seeded CPU generator):
   5b        BASELINE.json configs[1] literally: Yume-5B (30 live blocks + head), latent [48,13,44,80], FramePack lfz=8, L = 9460,
             77 text tokens, sigma index 10 of the 50-step shift-7 schedule, per-token timesteps (sample_5b.py:965-972), one forward
             (wan23/modules/model.py:547-865) and the Euler update of the 8 new frames (sample_5b.py:985-990).
-  14b       Yume-I2V-14B (40 live blocks + head) at reduced length: latent [16,13,28,28] + y [20,13,28,28] (L = 2254), CLIP features,
+  14b       Yume-I2V-14B (40 live blocks + head) at reduced length: latent [16,13,20,20] + y [20,13,20,20] (L = 1150), CLIP features,
             rand_num_img 0.6 / lfz 9 (FramePack path), CFG 5.0 = two forwards (wan/modules/model.py:723-1013; sample.py:774-790).
   5b_chain  the 5b case at a quarter of the area (latent [48,13,22,40], L = 2365) for multi-step drift records (tools/chain_drift.py).
 
@@ -34,7 +34,7 @@ SEED = 77
 CASES = {
     "5b": dict(family="wan23", F=13, H=44, W=80, lfz=8, steps=50, shift=7.0, i=10, n_text=77),
     "5b_chain": dict(family="wan23", F=13, H=22, W=40, lfz=8, steps=4, shift=7.0, i=0, n_text=77),
-    "14b": dict(family="wan", F=13, H=28, W=28, lfz=9, steps=50, shift=3.0, i=10, n_text=77, guide=5.0, rand_num_img=0.6),
+    "14b": dict(family="wan", F=13, H=20, W=20, lfz=9, steps=50, shift=3.0, i=10, n_text=77, guide=5.0, rand_num_img=0.6),
     # plumbing checks of this file on the build container (tests/test_step_job_cpu.py): 2-layer models of width 512
     "tiny5b": dict(family="wan23", F=13, H=12, W=16, lfz=8, steps=50, shift=7.0, i=10, n_text=20, tiny=True),
     "tiny14b": dict(family="wan", F=13, H=12, W=16, lfz=9, steps=50, shift=3.0, i=10, n_text=20, guide=5.0, rand_num_img=0.6, tiny=True),

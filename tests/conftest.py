@@ -31,38 +31,35 @@ def load_golden(name):
 
 
 # ---------------------------------------------------------------------------------------------- full-depth oracle jobs (row N1)
-# The CPU legs of tests/test_zz_full_step_gpu.py cost minutes (a whole 30-block 5B step at L = 9460 in fp32 is 118.8 TFLOP). They are
-# started as subprocesses (oracle/step_job.py, 32 host threads each) when a GPU session begins and collected by the tests that sort
-# last, so they overlap with the rest of the GPU suite instead of adding their length to it.
+# The CPU legs of tests/test_zz_full_step_gpu.py cost minutes (a whole 30-block 5B step at L = 9460 in fp32 is 118.8 TFLOP). They run as
+# subprocesses (oracle/step_job.py), all three side by side, started when THAT module begins (it sorts last) and collected by its tests
+# while the device legs run. (Round 4, first attempt: started at session begin to overlap with the whole suite — 128 busy host threads
+# next to the other tests' own CPU references, which run on torch's default of every hardware thread, oversubscribed the box: the suite
+# went from 5 to 20 minutes.)
 _STEP_JOBS = {}
 
 
+def start_step_jobs():
+    for name, which, threads in (("5b", "cond", 96), ("14b", "cond", 32), ("14b", "uncond", 32)):
+        if (name, which) not in _STEP_JOBS:
+            _start_step_job(name, which, threads)
+
+
 def step_job_result(name, which):
-    """block until the oracle forward (case, which) started at session begin is done -> its saved dict."""
+    """block until the oracle forward (case, which) is done -> its saved dict."""
     from oracle import step_job
     key = (name, which)
-    if key not in _STEP_JOBS:                     # e.g. the test was selected alone with -k after collection: start it now
-        _start_step_job(name, which)
+    if key not in _STEP_JOBS:
+        _start_step_job(name, which, 64)
     proc, out = _STEP_JOBS[key]
     return step_job.finish_job(proc, out)
 
 
-def _start_step_job(name, which):
+def _start_step_job(name, which, threads):
     import tempfile
     from oracle import step_job
     out = os.path.join(tempfile.gettempdir(), f"yume_step_{name}_{which}_{os.getpid()}.pt")
-    # (64 threads for the 118.8 TFLOP 5B step, 32 for each of the two 14B forwards: 128 of the GPU box's 256 hardware threads)
-    _STEP_JOBS[(name, which)] = (step_job.start_job(name, which, out, threads=64 if name == "5b" else 32), out)
-
-
-def pytest_collection_finish(session):
-    import torch
-    if not torch.cuda.is_available():
-        return
-    wanted = {it.fspath.basename for it in session.items}
-    if "test_zz_full_step_gpu.py" in wanted and not session.config.option.collectonly:
-        for name, which in (("5b", "cond"), ("14b", "cond"), ("14b", "uncond")):
-            _start_step_job(name, which)
+    _STEP_JOBS[(name, which)] = (step_job.start_job(name, which, out, threads=threads), out)
 
 
 def pytest_sessionfinish(session, exitstatus):

@@ -336,7 +336,7 @@ def test_attention_persistent_kernel_matches_exact_softmax_and_variant_7(Lq, Lk,
     if Lk >= 1536:
         assert torch.equal(auto, got)
     else:
-        assert rel_l2(auto.float(), got.float()) < 3e-3
+        assert rel_l2(auto.float(), got.float()) < 6e-3         # two kernels, two bf16 roundings of P and of O
 
 
 def test_attention_persistent_kernel_accumulate_and_repeated_launches():
