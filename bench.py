@@ -131,7 +131,7 @@ def vae_cpu_baseline():
         dt = time.time() - t0
     assert torch.isfinite(out).all()
     tf = fc.get_total_flops() / 1e12
-    torch.set_num_threads(os.cpu_count() or 1)
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
     return {"value": (tf / dt) / (485.04 / 8.0), "unit": "latents/s", "cores": ncore, "host_threads": os.cpu_count(), "kind": "port",
             "sample": f"oracle decode of 2 latents 48x2x6x10 ({tf:.2f} TFLOP, {dt:.2f} s = {tf / dt:.2f} TFLOP/s fp32), "
                       "scaled by FLOPs to the 704x1280 chunk (60.6 TFLOP per latent)"}
@@ -163,7 +163,10 @@ def cpu_baseline(cfg, L, model):
     torch.set_num_threads(best)
     case = fullsize.make_block_case(cfg, "wan23", L, seed=0)
     want, dt = fullsize.run_block_oracle(case)
-    torch.set_num_threads(ncpu)
+    # (not back to every hardware thread: the host side of the engine is small tensor ops, and with the whole-step oracle running as a
+    # subprocess next to the side workloads a 256-thread OpenMP team in THIS process is oversubscription — measured: seconds per first use
+    # of a new clip geometry in the long-video workload)
+    torch.set_num_threads(min(16, ncpu))
     tf = block_flops_5b(L, cfg) / dt / 1e12
     base = {"value": 1.0 / (dt * cfg["num_layers"]), "unit": "denoise-steps/sec", "cores": best, "host_threads": ncpu, "kind": "port",
             "sample": f"1 of {cfg['num_layers']} DiT blocks at L={L} (fp32, {dt:.2f} s = {tf:.2f} TFLOP/s on {best} of {ncpu} host threads), "
