@@ -30,7 +30,7 @@ DEV = "cuda"
 
 @pytest.fixture(scope="module", autouse=True)
 def _oracle_jobs():
-    """all three CPU legs side by side (96 + 32 + 32 host threads) from the moment this module starts; the tests below run their device legs
+    """all three CPU legs side by side (32 host threads each) from the moment this module starts; the tests below run their device legs
     first and then collect: the stack test needs none, the 14B jobs are the short ones, the 5B step is collected last."""
     start_step_jobs()
     yield
