@@ -48,8 +48,9 @@ const char* yume_target_arch(void);
  * buffer the CALLER owns: yume_counter_workspace_bytes() bytes, 64-byte aligned, registered once per device with
  * yume_counter_workspace_init(ptr, bytes, stream) — the call zeroes it on `stream` — and valid until it is replaced or unregistered
  * (ptr = NULL). Invariant: the buffer holds zeros whenever no launch is using it (the last workgroup of a launch to touch its 64-byte
- * counter set writes the zeros back), so launches need no memset and can be captured into a hipGraph. A set is shared by two launches
- * only if 256 ticketed launches of one device are in flight at once. Without a registered buffer the ticketed kernels keep their static
+ * counter set writes the zeros back), so launches need no memset and can be captured into a hipGraph (the set a launch uses is chosen when
+ * the launch is enqueued — at capture time for a graph: two replays of ONE captured graph must not run concurrently, as for any graph whose
+ * kernels share scratch). Otherwise a set is shared by two launches only if 256 ticketed launches of one device are in flight at once. Without a registered buffer the ticketed kernels keep their static
  * schedules (same results). The registration is per process and per device (the calling thread's current device). */
 int64_t yume_counter_workspace_bytes(void);
 int yume_counter_workspace_init(void* ptr, int64_t bytes, void* stream);
