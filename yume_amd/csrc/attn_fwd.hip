@@ -1023,7 +1023,7 @@ static bool attn7_applies(int64_t Lq, int64_t Lk) { return Lk >= 1536 && Lq >= Q
 // ---- launch plan of the persistent kernel (attn_fwd8.hip) ------------------------------------------------------------------
 // The same item list as attn_fwd7's (whole query blocks, then the key-range pieces of the last `nq - tail_qb` blocks of every head), drawn
 // by ticket instead of dispatched in block-id order. An item boundary costs ~2.5 tile times there (two bubbles) instead of a whole prologue
-// and epilogue, so shorter pieces pay: down to 5 key tiles.
+// and epilogue, so shorter pieces pay: down to 8 key tiles (what the GPU tests exercise; the kernel's own protocol needs 5).
 static Plan7 attn8_plan_search(int64_t Lq, int64_t Lk, int64_t H) {
     const int64_t nq = (Lq + QB4 - 1) / QB4, hx = (H + 7) / 8, nt = (Lk + KT - 1) / KT;
     Plan7 best{nq, 1};
@@ -1044,7 +1044,7 @@ static Plan7 attn8_plan_search(int64_t Lq, int64_t Lk, int64_t H) {
     };
     double bm = makespan(0, 1);
     for (int splits = 2; splits <= 4; ++splits) {
-        if (nt / splits < 5) break;                  // (an item of the stream is at least 5 tiles: its successor's ticket is drawn while it runs)
+        if (nt / splits < 8) break;                  // (an item of the stream is at least 8 tiles: its successor's ticket is drawn while it runs, with room)
         for (int64_t tail_q = 1; tail_q <= nq && tail_q <= 12; ++tail_q) {
             const double m = makespan(tail_q, splits);
             if (m < bm - 0.01 * whole) { bm = m; best = Plan7{nq - tail_q, splits}; }
