@@ -175,7 +175,22 @@ static size_t where_differs(const Prob& p, const std::vector<uint16_t>& a, const
             char& f = cell[(i / 256) * p.H + c / 128];
             if (!f) { f = 1; ++cells; }
         }
-    if (nd) printf("      %zu values differ in %zu of %zu (block, head) cells\n", nd, cells, cell.size());
+    if (nd) {
+        printf("      %zu values differ in %zu of %zu (block, head) cells\n", nd, cells, cell.size());
+        // by wave of the 256-query workgroup and by its two 32-query blocks (A = lane rows 0..31, B = 32..63), and by size in bf16 ulps of the larger value
+        size_t byw[4][2] = {}, ulp[4] = {};
+        for (int64_t i = 0; i < p.Lq; ++i)
+            for (int64_t c = 0; c < p.H * 128; ++c) {
+                const size_t ix = i * p.ldo + c;
+                if (a[ix] == b[ix]) continue;
+                ++byw[(i % 256) / 64][(i % 64) / 32];
+                const float x = bf2f(a[ix]), y = bf2f(b[ix]), m = fmaxf(fabsf(x), fabsf(y));
+                const float u = m > 0 ? fabsf(x - y) / (m * 0.0078125f) : 0.f;
+                ++ulp[u <= 1.01f ? 0 : u <= 2.01f ? 1 : u <= 8.f ? 2 : 3];
+            }
+        printf("      by wave x block (A B): w0 %zu %zu | w1 %zu %zu | w2 %zu %zu | w3 %zu %zu;  <=1 ulp %zu, 2 ulp %zu, <=8 ulp %zu, more %zu\n", byw[0][0], byw[0][1],
+               byw[1][0], byw[1][1], byw[2][0], byw[2][1], byw[3][0], byw[3][1], ulp[0], ulp[1], ulp[2], ulp[3]);
+    }
     return nd;
 }
 static double maxdiff2(const std::vector<uint16_t>& a, const std::vector<uint16_t>& b, int* nan) {
