@@ -1166,7 +1166,8 @@ extern "C" int yume_attn_fwd_ws(const void* Q, int64_t ldq, const void* K, int64
     // the persistent kernel (attn_fwd8.hip): base-free body only, K / V^T padded to whole key tiles (the caller's word: YUME_ATTN_KV_PADDED;
     // ldvt can be checked), a registered counter workspace for its tickets. variant 8 insists on it, variant 0 takes it where it applies.
     const int64_t nt8 = (Lk + KT - 1) / KT;
-    const bool v8_fits = q_pre && kv_pad && attn8_applies(Lq, Lk) && ldvt >= nt8 * KT;
+    const bool v8_fits = q_pre && kv_pad && attn8_applies(Lq, Lk) && ldvt >= nt8 * KT &&
+                         Lq * ldq * 2 + 512 < (1ll << 32);      // (its Q' loads address a query row by a 32-bit byte offset from the head's base)
     if (variant == 8) {
         YUME_REQUIRE(v8_fits, "attn_fwd: variant 8 needs YUME_ATTN_Q_PRESCALED | YUME_ATTN_KV_PADDED, Lk >= 512, Lq >= 256 and ldvt >= %lld",
                      (long long)(nt8 * KT));
