@@ -9,6 +9,7 @@ fill_module_hashed_, bit for bit; inputs from a seeded CPU generator):
             (wan23/modules/model.py:547-865) and the Euler update of the 8 new frames (sample_5b.py:985-990).
   14b       Yume-I2V-14B (40 live blocks + head) at reduced length: latent [16,13,20,20] + y [20,13,20,20] (L = 1150), CLIP features,
             rand_num_img 0.6 / lfz 9 (FramePack path), CFG 5.0 = two forwards (wan/modules/model.py:723-1013; sample.py:774-790).
+  14b_full  BASELINE.json configs[2] literally: latent [16,17,68,120] + y, L = 27 810, 40 live blocks, CFG 5.0 (row N2; device gold only).
   5b_chain  the 5b case at a quarter of the area (latent [48,13,22,40], L = 2365) for multi-step drift records (tools/chain_drift.py).
 
 The CPU leg costs minutes (5b: 118.8 TFLOP in fp32), so it runs as a SUBPROCESS next to the GPU work:
@@ -35,6 +36,9 @@ CASES = {
     "5b": dict(family="wan23", F=13, H=44, W=80, lfz=8, steps=50, shift=7.0, i=10, n_text=77),
     "5b_chain": dict(family="wan23", F=13, H=22, W=40, lfz=8, steps=4, shift=7.0, i=0, n_text=77),
     "14b": dict(family="wan", F=13, H=20, W=20, lfz=9, steps=50, shift=3.0, i=10, n_text=77, guide=5.0, rand_num_img=0.6),
+    # BASELINE.json configs[2] literally (bench.py::bench_14b): 65-frame 544x960 clip, latent [16,17,68,120] + y, L = 27 810. Its oracle leg is
+    # 2.6 PFLOP per CFG step: only the device gold (oracle/devgold.py, the same functions on the GPU in fp32) can afford it.
+    "14b_full": dict(family="wan", F=17, H=68, W=120, lfz=9, steps=50, shift=3.0, i=10, n_text=77, guide=5.0, rand_num_img=0.6),
     # plumbing checks of this file on the build container (tests/test_step_job_cpu.py): 2-layer models of width 512
     "tiny5b": dict(family="wan23", F=13, H=12, W=16, lfz=8, steps=50, shift=7.0, i=10, n_text=20, tiny=True),
     "tiny14b": dict(family="wan", F=13, H=12, W=16, lfz=9, steps=50, shift=3.0, i=10, n_text=20, guide=5.0, rand_num_img=0.6, tiny=True),
@@ -86,12 +90,16 @@ def euler(name, latent, pred, i):
 class _TimedSD:
     """HashedDitStateDict with the generation time kept apart from the forward's own time."""
 
-    def __init__(self, sd):
-        self.sd, self.gen_s = sd, 0.0
+    def __init__(self, sd, sync=False):
+        self.sd, self.gen_s, self.sync = sd, 0.0, sync
 
     def __getitem__(self, k):
+        if self.sync:
+            torch.cuda.synchronize()
         t0 = time.time()
         v = self.sd[k]
+        if self.sync:
+            torch.cuda.synchronize()
         self.gen_s += time.time() - t0
         return v
 
@@ -103,34 +111,46 @@ class _TimedSD:
 
 
 @torch.no_grad()
-def oracle_forward(name, which, latent=None, i=None, threads=None):
-    """one reference-restatement forward of the case on the host -> (pred fp32 [Cout, lfz, H, W], forward seconds, weight-generation seconds)."""
+def oracle_forward(name, which, latent=None, i=None, threads=None, device=None):
+    """one reference-restatement forward of the case -> (pred fp32 [Cout, lfz, H, W] on the host, forward seconds, weight-generation seconds).
+    device None: on the host cores (the specification). device "cuda": the same oracle/dit.py functions on the GPU in fp32 — the device gold
+    of oracle/devgold.py (weights from the same hashed rule evaluated on the GPU, bit for bit), for the sizes the host cannot afford."""
+    import contextlib
     from yume_amd import synth
+    from . import devgold
     from . import dit as odit
     from . import fullsize
     c = CASES[name]
     cfg = case_cfg(name)
     if threads:
         torch.set_num_threads(threads)
-    inp = make_inputs(name)
-    latent = inp["latent"] if latent is None else latent
+    on_gpu = device is not None                    # (device="cpu" runs the device-gold code path on the host: its plumbing test)
+    dev = torch.device(device) if on_gpu else torch.device("cpu")
+    cuda = dev.type == "cuda"
+    inp = {k: v.to(dev) for k, v in make_inputs(name).items()}
+    latent = inp["latent"] if latent is None else latent.to(dev)
     i = c["i"] if i is None else i
     plan = seq_len(name)
     sg = sigmas(name)
-    sd = _TimedSD(synth.HashedDitStateDict(cfg, c["family"], SEED))
+    sd = _TimedSD(synth.HashedDitStateDict(cfg, c["family"], SEED, device=dev), sync=cuda)
     orig = odit.attention
-    odit.attention = fullsize.attention_fp32
+    if not on_gpu:
+        odit.attention = fullsize.attention_fp32
     try:
-        t0 = time.time()
-        if c["family"] == "wan23":
-            t = torch.cat([torch.zeros(plan.n_hist_tok, dtype=torch.float64),
-                           torch.full((plan.n_new_tok,), sg[i] * 1000.0, dtype=torch.float64)]).unsqueeze(0)
-            pred = odit.forward_wan23(sd, cfg, latent, t, inp[which], plan.seq_len, c["lfz"], True)
-        else:
-            t = torch.tensor([sg[i] * 1000.0])
-            pred = odit.forward_wan(sd, cfg, latent, t, inp[which], plan.seq_len, inp["clip_fea"][0], inp["y"],
-                                    rand_num_img=c["rand_num_img"], latent_frame_zero=c["lfz"])
-        dt = time.time() - t0
+        with (devgold.on_device(dev, force=not cuda) if on_gpu else contextlib.nullcontext()):
+            if cuda:
+                torch.cuda.synchronize()
+            t0 = time.time()
+            if c["family"] == "wan23":
+                t = torch.cat([torch.zeros(plan.n_hist_tok, dtype=torch.float64),
+                               torch.full((plan.n_new_tok,), sg[i] * 1000.0, dtype=torch.float64)]).unsqueeze(0).to(dev)
+                pred = odit.forward_wan23(sd, cfg, latent, t, inp[which], plan.seq_len, c["lfz"], True)
+            else:
+                t = torch.tensor([sg[i] * 1000.0], device=dev)
+                pred = odit.forward_wan(sd, cfg, latent, t, inp[which], plan.seq_len, inp["clip_fea"][0], inp["y"],
+                                        rand_num_img=c["rand_num_img"], latent_frame_zero=c["lfz"])
+            pred = pred.cpu()                                   # (synchronises)
+            dt = time.time() - t0
     finally:
         odit.attention = orig
     return pred, dt - sd.gen_s, sd.gen_s

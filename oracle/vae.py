@@ -233,7 +233,7 @@ def unpatchify(x, p):
 @torch.no_grad()
 def encode(sd, cfg, video):
     """WanVAE_.encode + wrapper (vae2_2.py:797-829,1045-1057): video [3, T, H, W] in [-1,1] -> latent fp32 [z, T', h, w]."""
-    mean, inv_std = latent_scale(cfg["version"])
+    mean, inv_std = (t.to(video.device) for t in latent_scale(cfg["version"]))
     x = patchify(video.float(), cfg["patch"])
     T = x.shape[1]
     cache, outs = Cache(), []
@@ -248,7 +248,7 @@ def encode(sd, cfg, video):
 @torch.no_grad()
 def decode(sd, cfg, z):
     """WanVAE_.decode + wrapper (vae2_2.py:831-860,1059-1072): latent [z, T, h, w] -> video fp32 [3, 1+4(T-1), H, W] in [-1,1]."""
-    mean, inv_std = latent_scale(cfg["version"])
+    mean, inv_std = (t.to(z.device) for t in latent_scale(cfg["version"]))
     z = z.float() / inv_std.view(-1, 1, 1, 1) + mean.view(-1, 1, 1, 1)
     x = F.conv3d(z.unsqueeze(0), sd["conv2.weight"], sd["conv2.bias"])[0]
     cache, outs = Cache(), []

@@ -32,10 +32,11 @@ def load_golden(name):
 
 # ---------------------------------------------------------------------------------------------- full-depth oracle jobs (row N1)
 # The CPU legs of tests/test_zz_full_step_gpu.py cost minutes (a whole 30-block 5B step at L = 9460 in fp32 is 118.8 TFLOP). They run as
-# subprocesses (oracle/step_job.py), all three side by side on 32 host threads each, started when THAT module begins (it sorts last) and collected by its tests
-# while the device legs run. (Round 4, first attempt: started at session begin to overlap with the whole suite — 128 busy host threads
-# next to the other tests' own CPU references, which run on torch's default of every hardware thread, oversubscribed the box: the suite
-# went from 5 to 20 minutes.)
+# subprocesses (oracle/step_job.py), side by side on 32 host threads each, started when THAT module begins (it sorts last) and collected by
+# its tests while the device legs and the device gold run. (Round 4, first attempt: started at session begin to overlap with the whole
+# suite — 128 busy host threads next to the other tests' own CPU references, which run on torch's default of every hardware thread,
+# oversubscribed the box: the suite went from 5 to 20 minutes. Round 5: two jobs instead of three — the 14B uncond leg and the
+# full-length 14B case are held to the device gold, oracle/devgold.py, which the two CPU jobs prove.)
 _STEP_JOBS = {}
 _STEP_JOBS_T0 = [0.0]
 
@@ -43,18 +44,19 @@ _STEP_JOBS_T0 = [0.0]
 def start_step_jobs():
     # 32 threads each: measured on the GPU box, the 118.8 TFLOP 5B step takes 229 s on 32 threads alone and 440 s on 64 or 96 threads next
     # to two other jobs — torch's CPU GEMMs stop scaling there and the jobs fight for memory bandwidth
-    for name, which, threads in (("5b", "cond", 32), ("14b", "cond", 32), ("14b", "uncond", 32)):
+    for name, which, threads in (("5b", "cond", 32), ("14b", "cond", 32)):
         if (name, which) not in _STEP_JOBS:
             _start_step_job(name, which, threads)
 
 
-STEP_JOB_DEADLINE_S = 600     # from the start of the jobs; a host too slow for that skips the comparison BY NAME instead of eating the suite's time limit
+STEP_JOB_DEADLINE_S = 600     # from the start of the jobs
 
 
 def step_job_result(name, which):
-    """block until the oracle forward (case, which) is done -> its saved dict. The three jobs together are ~5 minutes of a GPU box's host; a host
-    that has not finished a job STEP_JOB_DEADLINE_S after their start (another tenant, a throttled CPU) makes the test skip with a message
-    that says so — the suite has a wall-clock limit and the same comparison is in bench.py's `parity.full_step`."""
+    """block until the oracle forward (case, which) is done -> its saved dict. The jobs are ~4 minutes of a GPU box's host. A host that
+    has not finished a job STEP_JOB_DEADLINE_S after their start (another tenant, a throttled CPU) FAILS the test by name: the whole-step
+    comparison against the CPU oracle is the suite's key parity row and must not turn green by not running.
+    YUME_FULL_STEP_ALLOW_SKIP=1 is the explicit opt-out (a named skip) for a host known to be too slow."""
     import subprocess
     import time
     from oracle import step_job
@@ -66,8 +68,11 @@ def step_job_result(name, which):
     try:
         return step_job.finish_job(proc, out, timeout=left)
     except subprocess.TimeoutExpired:
-        pytest.skip(f"the CPU oracle job {name}/{which} has not finished {STEP_JOB_DEADLINE_S} s after its start on this host "
-                    "(run tests/test_zz_full_step_gpu.py alone, or read bench.py's parity.full_step)")
+        msg = (f"the CPU oracle job {name}/{which} has not finished {STEP_JOB_DEADLINE_S} s after its start on this host "
+               "(run tests/test_zz_full_step_gpu.py alone, or read bench.py's parity.full_step)")
+        if os.environ.get("YUME_FULL_STEP_ALLOW_SKIP", "0") == "1":
+            pytest.skip(msg + " — skipped because YUME_FULL_STEP_ALLOW_SKIP=1")
+        pytest.fail(msg + "; set YUME_FULL_STEP_ALLOW_SKIP=1 to turn this into a skip")
 
 
 def _start_step_job(name, which, threads):
