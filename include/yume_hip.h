@@ -160,12 +160,17 @@ int yume_rmsnorm_rows_periodic(void* buf, int64_t ld, int64_t T, int64_t C, cons
  */
 #define YUME_ATTN_Q_PRESCALED 0x100
 /*    | YUME_ATTN_KV_PADDED: the caller guarantees that K has at least ceil(Lk/64)*64 readable rows (whatever they hold) and that Vt has
- *    ldvt >= ceil(Lk/64)*64 with FINITE values in the columns >= Lk (they are multiplied by exact zeros). Together with
- *    YUME_ATTN_Q_PRESCALED, Lk >= 512, Lq >= 256 and a registered counter workspace this lets variant 0 take the persistent kernel
- *    (attn_fwd8.hip: one resident workgroup per CU draws (head, query block) items by ticket and streams K / V^T tiles continuously
- *    across them — the ragged last key tile is fetched like any other and only masked); variant 8 insists on that kernel. Same
- *    arithmetic per key tile in the same order as variant 7: whole query blocks are bit-identical. env YUME_ATTN_V8=0 keeps variant 0
- *    off it (A/B runs). */
+ *    ldvt >= ceil(Lk/64)*64 with FINITE values in the columns >= Lk (they are multiplied by exact zeros). It opens the persistent
+ *    kernel (attn_fwd8.hip: one resident workgroup per CU draws (head, query block) items by ticket and streams K / V^T tiles
+ *    continuously across them — the ragged last key tile is fetched like any other and only masked). Which calls take it:
+ *      variant 0 (automatic): both flags AND Lk >= 1536 AND Lq >= 256 (where variant 0 would take the one-wave-per-SIMD kernel at all;
+ *        the 512-key cross-attention stays on the 4-wave kernel, which measured faster there) AND a registered counter workspace
+ *        (yume_counter_workspace_init) AND Lq * ldq * 2 + 512 < 2^32 (the kernel addresses a query row by a 32-bit byte offset from
+ *        its head's base). A call that misses one of these runs variant 7 / 2 as before — silently, it is the same function;
+ *        env YUME_ATTN_V8=0 keeps variant 0 off the persistent kernel (A/B runs);
+ *      variant 8: insists on it — both flags, Lk >= 512, Lq >= 256, the workspace and the 32-bit limit are then REQUIRED (YUME_EINVAL
+ *        by name otherwise). It is the only way to run the persistent kernel for 512 <= Lk < 1536.
+ *    Same arithmetic per key tile in the same order as variant 7: whole query blocks are bit-identical. */
 #define YUME_ATTN_KV_PADDED 0x200
 int yume_attn_fwd(const void* Q, int64_t ldq, const void* K, int64_t ldk, const void* Vt, int64_t ldvt,
                   void* O, int64_t ldo, int64_t Lq, int64_t Lk, int64_t H, float scale,

@@ -106,3 +106,26 @@ def test_bench_gpus_n_without_enough_gpus_refuses_by_name():
         pytest.skip("multi-GPU node")
     assert r.returncode != 0
     assert "--gpus 2 requested but this node shows" in r.stderr and "{" not in r.stdout
+
+
+def _one_rank_worker(rank, world, port):
+    os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from yume_amd import distributed as D
+    dist.init_process_group("gloo")
+    net = TinyNet(seed=7)
+    ref = TinyNet(seed=7)
+    assert D.broadcast_module_(net) == 0                                    # a one-rank group has nothing to replicate ...
+    n1 = D.broadcast_module_(net, bucket_bytes=64 * 1024, force=True)       # ... unless forced (the single-GPU RCCL test drives it so)
+    n2 = D.broadcast_module_(net, bucket_bytes=64 * 1024, mode="scatter_allgather", force=True)
+    assert n1 >= 3 and n2 == 2 * n1
+    for (k, p), (_, q) in zip(net.state_dict().items(), ref.state_dict().items()):
+        assert torch.equal(p, q), k
+    t = torch.randn(3, 4)
+    assert torch.equal(D.all_gather_results(t, force=True), t.unsqueeze(0))
+    assert D.gather_scalars(2.5, force=True) == [2.5]
+    dist.destroy_process_group()
+
+
+def test_forced_collectives_in_a_one_rank_group():
+    """the `force` switch tests/test_distributed_gpu.py uses to run every RCCL call of the N > 1 path on the single-GPU box, here over gloo."""
+    mp.spawn(_one_rank_worker, args=(1, _free_port()), nprocs=1, join=True)

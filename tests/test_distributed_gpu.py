@@ -57,6 +57,55 @@ def test_two_rank_rccl_replication_and_independent_chains(tmp_path):
     assert torch.equal(a, b)                                     # both ranks gathered the same pair of results
 
 
+def _one_rank_worker(rank, world, port, out_dir):
+    os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch.distributed as dist
+    from yume_amd import distributed as D, synth
+    from yume_amd.wan23.modules.model import WanModel
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", device_id=dev)               # RCCL communicator of one rank on the test box's one GPU
+    assert dist.get_backend() == "nccl" and dist.get_world_size() == 1
+    cfg = synth.tiny_cfg("wan23")
+    with torch.device(dev):
+        m = WanModel(**cfg)
+    synth.randomize_module_(m, seed=10)
+    m = m.to(torch.bfloat16)
+    before = [p.detach().clone() for p in m.parameters()]
+    nparam = sum(p.numel() * p.element_size() for p in m.parameters())
+    n1 = D.broadcast_module_(m, src=0, bucket_bytes=1 << 20, force=True)                 # several 1 MiB device buckets -> dist.broadcast each
+    assert n1 >= max(2, nparam // (1 << 20) // 2), (n1, nparam)
+    n2 = D.broadcast_module_(m, src=0, bucket_bytes=1 << 20, mode="scatter_allgather", force=True)   # dist.scatter + all_gather_into_tensor
+    assert n2 == 2 * n1
+    torch.cuda.synchronize()
+    assert all(torch.equal(a, b) for a, b in zip(before, m.parameters()))                # the round trip through the flat buckets is exact
+    lat = torch.randn((48, 8, 12, 16), device=dev)
+    allr = D.all_gather_results(lat, force=True)                                         # dist.all_gather on a device tensor
+    assert allr.shape == (1, 48, 8, 12, 16) and torch.equal(allr[0], lat)
+    chk = D.gather_scalars(3.25, device=dev, force=True)
+    assert chk == [3.25]
+    t = torch.tensor([1.5], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)                                             # bench.py's max-over-ranks timing collective
+    dist.barrier()
+    assert float(t) == 1.5
+    with open(os.path.join(out_dir, "ok"), "w") as f:
+        f.write(f"{n1} {n2}")
+    dist.destroy_process_group()
+
+
+def test_one_rank_rccl_communicator_drives_every_collective_of_the_multi_gpu_path(tmp_path):
+    """no multi-GPU node exists for the builder, but the RCCL calls of the N > 1 path — communicator creation, the bucketed
+    weight broadcast in both modes, the result all-gather, the scalar gather, the timing all-reduce and the barrier — run here through a
+    real `backend="nccl"` group of ONE rank on device tensors, so that the driver's first N = 8 run is not also their first contact with
+    RCCL (fastvideo/sample/sample_5b.py:1124-1134 is the launch being mirrored)."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_one_rank_worker, args=(1, port, str(tmp_path)), nprocs=1, join=True)
+    assert (tmp_path / "ok").exists()
+
+
 def _run_bench(extra_args, env_extra, timeout=900):
     import json
     import subprocess

@@ -375,6 +375,14 @@ def test_attention_persistent_kernel_out_of_range_items_rerun_on_the_robust_piec
     assert torch.isfinite(got).all()
     assert (got.double() - want).abs().max() <= 2e-2 * want.abs().max()
     assert rel_l2(got, want) < 6e-3
+    # determinism of the rerun path: the robust rerun inside the persistent launch shares LDS and the DMA queue with the stream
+    # it interrupts; twenty more launches on the same data have to give the same bits as the first, in the rerun items and around them
+    for _ in range(20):
+        assert torch.equal(run_attn_padded(qp, k, v), got)
+    # ... and the fallback kernel (attn_fwd7: same rerun pieces, no stream) is deterministic on the same data as well
+    v7 = run_attn(qp, k, v, variant=7, q_prescaled=True)
+    for _ in range(5):
+        assert torch.equal(run_attn(qp, k, v, variant=7, q_prescaled=True), v7)
 
 
 def test_attention_persistent_kernel_refuses_what_it_cannot_take():

@@ -174,50 +174,11 @@ __device__ __forceinline__ void store_partial8(const AttnArgs& p, const Blk& x, 
     }
 }
 
-// The same block through LDS as WHOLE ROWS. A lane of the O^T layout holds 4 consecutive d of one query: its 16 stores per block write 8 bytes
-// each into 32 different rows — 512 partial-line writes per instruction stream, and the four waves of a workgroup queue them on one
-// memory pipe: 5 - 6 us per item, measured (profiles/r4_trace_attention_v8_item_boundary_v3.txt). Here a wave transposes half a block at a time
-// (32 queries x 64 d, bf16) through a private 32 x 136-byte LDS patch (8 bytes of padding per row: two-way bank conflicts at worst) and
-// stores 16 bytes per lane, 8 lanes per 128-byte row segment: 4 store instructions of 8 whole line segments per half block. Same values,
-// same rounding. Not for `accumulate` (that path adds in fp32 before it rounds) and not for an O that is not 16-byte aligned.
-constexpr int OSTAGE_ROW = 136, OSTAGE_WAVE = 32 * OSTAGE_ROW;
-template <int XO>
-__device__ __forceinline__ void store_block8_rows(const AttnArgs& p, const Blk& x, int qrow0, int h, char* stage) {
-    const float l_tot = xhalf_sum(x.z.l_run);
-    const float inv = 1.0f / l_tot;
-    const unsigned l = fresh_lane();
-    const unsigned ql = l & 31, hi = l >> 5;
-    char* wr = stage + ql * OSTAGE_ROW + hi * 8;
-    const char* rd = stage + (l >> 3) * OSTAGE_ROW + (l & 7) * 16;
-    unsigned short* orow = p.O + (int64_t)(qrow0 + (int)(l >> 3)) * p.ldo + h * D + (l & 7) * 8;
-    for_regs<0, 2>([&](auto hc) {
-        constexpr int half = decltype(hc)::value;
-        for_regs<0, 2>([&](auto dc) {
-            constexpr int db = 2 * half + decltype(dc)::value;
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                float v[4];
-                for_regs<0, 4>([&](auto j) { v[decltype(j)::value] = 0.f; });
-                // (the AGPR numbers have to be literals: one instance per g)
-                if (g == 0) for_regs<0, 4>([&](auto j) { v[decltype(j)::value] = agpr_get<XO + 16 * db + 0 + decltype(j)::value>() * inv; });
-                if (g == 1) for_regs<0, 4>([&](auto j) { v[decltype(j)::value] = agpr_get<XO + 16 * db + 4 + decltype(j)::value>() * inv; });
-                if (g == 2) for_regs<0, 4>([&](auto j) { v[decltype(j)::value] = agpr_get<XO + 16 * db + 8 + decltype(j)::value>() * inv; });
-                if (g == 3) for_regs<0, 4>([&](auto j) { v[decltype(j)::value] = agpr_get<XO + 16 * db + 12 + decltype(j)::value>() * inv; });
-                u32x2 w;
-                w[0] = pack_bf16x2(v[0], v[1]);
-                w[1] = pack_bf16x2(v[2], v[3]);
-                *reinterpret_cast<u32x2*>(wr + (32 * (db & 1) + 8 * g) * 2) = w;
-            }
-        });
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // this wave's own patch: no barrier
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const u32x4 row = *reinterpret_cast<const u32x4*>(rd + 8 * i * OSTAGE_ROW);
-            if (qrow0 + (int)(l >> 3) + 8 * i < p.Lq) *reinterpret_cast<u32x4*>(orow + (int64_t)(8 * i) * p.ldo + 64 * half) = row;
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the reads are done before the next half overwrites the patch
-    });
-}
+// (r4 built a whole-row variant of store_block8 — the O^T block transposed through a per-wave LDS patch into 128-byte row segments, worth
+// 1.1 us of the 5-6 us the lane-strided stores cost per item; it made the items that take the robust rerun differ by 1 bf16 ulp between two
+// launches on the same data (profiles/r4_attn8_rows_store_bisect.log), the cause was not found, and r5 removed the code instead of parking
+// it behind a macro: git show 89876aa:yume_amd/csrc/attn_fwd8.hip has it. tests/test_ops_gpu.py launches the rerun shapes twice and
+// compares bits, so a latent race in the shared rerun path would show.)
 
 // One tile of the stream on compile-time slots (TS = global tile counter & 3). KIND 0: attn_fwd7's steady tile. KIND 1: the tile before an
 // item's last — its second phase computes softmax_A of the last tile, masked against Lk (jl = first key of that tile). KIND 2: the last
@@ -288,7 +249,6 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_kernel_v8(AttnArgs p, int* cn
     __shared__ int votes[4];                           // the range vote of the four waves
     __shared__ int mail[2];                            // tickets drawn by thread 0, read by everybody behind a barrier
     __shared__ __attribute__((aligned(16))) int junk[4 * 128];   // where the Q' touch (below) drops what it fetched: 2 pieces x 256 B per wave
-    __shared__ __attribute__((aligned(16))) char ostage[4 * OSTAGE_WAVE];      // store_block8_rows: one 32 x 136-byte patch per wave
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -335,17 +295,6 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_kernel_v8(AttnArgs p, int* cn
     int kleft = 0, vleft = 0;       // tiles of the stream's current item still to fetch
     int g = 0;                      // tiles computed since the last cold start: tile g lives in slot g & 3
     int t = 0;                      // key tile (of cur) the next tile step computes
-    // whole-row stores of O^T (store_block8_rows): 16-byte accesses, no read-modify-write
-    // OFF in the product build (V8_ROWS_STORE, an experiment flag): with it, the items that took the robust rerun came out NON-DETERMINISTIC in
-    // their B blocks (tools/attn_check: differences between two launches on the same data, 1 bf16 ulp in ~15 % of those rows; every
-    // base-free item stayed bit-identical to attn_fwd7). Four builds bisected it to the EXECUTED whole-row path
-    // (profiles/r4_attn8_rows_store_bisect.log); the cause was not found in the time there was, and the gain was 1.1 us of the ~7 us
-    // of bubble 2 — so the stores stay the lane-strided ones of attn_fwd7.
-#ifdef V8_ROWS_STORE
-    const bool rows_ok = !p.accumulate && (reinterpret_cast<uintptr_t>(p.O) & 15) == 0 && (p.ldo & 7) == 0;
-#else
-    const bool rows_ok = false;
-#endif
     bool cold = true;
     bool first = false;             // the next tile step is the first behind an item boundary of the stream (KIND 3)
     const unsigned junk_lds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) int*)junk + wave * 512;
@@ -571,9 +520,6 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_kernel_v8(AttnArgs p, int* cn
             const int64_t rows = p.Lq - row0;
             store_partial8<OA>(p, A, q0 + ql, cur.h, hi, cur.sp, rows, row0);
             store_partial8<OB>(p, B, q0 + 32 + ql, cur.h, hi, cur.sp, rows, row0);
-        } else if (rows_ok) {
-            store_block8_rows<OA>(p, A, q0, cur.h, ostage + wave * OSTAGE_WAVE);
-            store_block8_rows<OB>(p, B, q0 + 32, cur.h, ostage + wave * OSTAGE_WAVE);
         } else {
             store_block8<OA>(p, A, q0 + ql, cur.h, hi);
             store_block8<OB>(p, B, q0 + 32 + ql, cur.h, hi);

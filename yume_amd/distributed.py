@@ -39,11 +39,12 @@ def shard_indices(n_items, rank, world):
 
 
 @torch.no_grad()
-def broadcast_module_(module, src=0, bucket_bytes=1 << 30, mode=None):
+def broadcast_module_(module, src=0, bucket_bytes=1 << 30, mode=None, force=False):
     """Replicate rank `src`'s parameters and buffers on every rank in flat buckets. mode "broadcast" = one dist.broadcast per
     bucket; "scatter_allgather" = dist.scatter of world slices + dist.all_gather_into_tensor (2 collectives per bucket; the
-    bucket is padded to a multiple of world). Default: YUME_WEIGHT_DIST env var, else "broadcast". Returns the collective count."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    bucket is padded to a multiple of world). Default: YUME_WEIGHT_DIST env var, else "broadcast". Returns the collective count.
+    force: issue the collectives in a one-rank group too (tests/test_distributed_gpu.py drives the RCCL calls on a single GPU)."""
+    if not dist.is_initialized() or (dist.get_world_size() == 1 and not force):
         return 0
     mode = mode or os.environ.get("YUME_WEIGHT_DIST", "broadcast")
     if mode not in ("broadcast", "scatter_allgather"):
@@ -88,19 +89,19 @@ def broadcast_module_(module, src=0, bucket_bytes=1 << 30, mode=None):
     return n_coll
 
 
-def all_gather_results(t):
+def all_gather_results(t, force=False):
     """[world, *t.shape]: every rank's result tensor (e.g. the [48,8,44,80] latents of its chain)."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not dist.is_initialized() or (dist.get_world_size() == 1 and not force):
         return t.unsqueeze(0)
     out = [torch.empty_like(t) for _ in range(dist.get_world_size())]
     dist.all_gather(out, t.contiguous())
     return torch.stack(out)
 
 
-def gather_scalars(x, device=None):
+def gather_scalars(x, device=None, force=False):
     """list of one python float per rank (timings, checksums)."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not dist.is_initialized() or (dist.get_world_size() == 1 and not force):
         return [float(x)]
     dev = device or (torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else "cpu")
     t = torch.tensor([float(x)], dtype=torch.float64, device=dev)
-    return [float(v) for v in all_gather_results(t).flatten()]
+    return [float(v) for v in all_gather_results(t, force).flatten()]

@@ -4,6 +4,7 @@ torch is used for device memory and the current HIP stream only: every function 
 its tensors, passes raw device pointers + sizes to libyume_hip.so and raises RuntimeError on failure.
 """
 import math
+import os
 
 import torch
 
@@ -36,21 +37,34 @@ def _ptr(t):
 
 
 _counters = {}
+_DEBUG_COUNTERS = os.environ.get("YUME_DEBUG_COUNTERS", "0") == "1"
 
 
 def ensure_counters(device):
     """Register (once per device) the caller-owned ticket-counter workspace of include/yume_hip.h (yume_counter_workspace_init): kernels
     that hand out work by ticket — long convolutions' tails, the persistent attention kernel — draw their counters from it; the library
-    itself allocates nothing. The tensor lives for the life of the process."""
+    itself allocates nothing. The tensor lives for the life of the process.
+    The zeroing is enqueued on the current stream and the DEVICE is synchronised before the workspace counts as registered: the first
+    ticketed launch may come from any stream. Inside a hipGraph capture the zeroing would be recorded, not executed — refused by name
+    (call yume_amd.ops.ensure_counters(device) once before capturing). YUME_DEBUG_COUNTERS=1: every call checks that the sets read zero
+    (every ticketed kernel puts its zeros back; a dirty set means a launch was killed half way)."""
     idx = device.index if device.index is not None else torch.cuda.current_device()
     t = _counters.get(idx)
     if t is None:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("yume_amd: the ticket-counter workspace must be registered before a stream capture begins "
+                               "(call yume_amd.ops.ensure_counters(device) once outside the capture)")
         lib = _lib.load()
         n = int(lib.yume_counter_workspace_bytes())
         with torch.cuda.device(idx):
             t = torch.zeros(n // 4, dtype=torch.int32, device=torch.device("cuda", idx))
             _lib.check(lib.yume_counter_workspace_init(t.data_ptr(), n, _stream()), "yume_counter_workspace_init")
+            torch.cuda.synchronize(idx)
         _counters[idx] = t
+    elif _DEBUG_COUNTERS and not torch.cuda.is_current_stream_capturing():
+        torch.cuda.synchronize(idx)
+        if int(t.abs().max()) != 0:
+            raise RuntimeError("yume_amd: the ticket-counter workspace is not zero between launches (YUME_DEBUG_COUNTERS=1)")
     return t
 
 
@@ -169,6 +183,18 @@ def attn_fwd(q, k, vt, out, Lq, Lk, H, scale=None, accumulate=False, variant=0, 
     kp, ldk = _rows(k, "k")
     vp, ldv = _rows(vt, "vt")
     op, ldo = _rows(out, "out")
+    if kv_padded:
+        # the caller's word is checked where the tensors can tell: V^T must HAVE the padded columns, and k's storage must
+        # cover the rows of the last whole tile (a tight view at the end of an allocation would be read out of bounds). That the padding
+        # is finite stays the caller's contract — dit.py keeps it in zero-filled buffers.
+        Lp = (Lk + 63) // 64 * 64
+        if vt.shape[1] < Lp:
+            raise RuntimeError(f"yume_amd.attn_fwd: kv_padded needs vt with >= {Lp} columns (ceil(Lk / 64) * 64), got {vt.shape[1]}")
+        need = k.storage_offset() + (Lp - 1) * ldk + H * 128
+        have = k.untyped_storage().nbytes() // k.element_size()
+        if need > have:
+            raise RuntimeError(f"yume_amd.attn_fwd: kv_padded needs k's storage to cover {Lp} rows (ceil(Lk / 64) * 64): the view ends "
+                               f"{need - have} elements short")
     if scale is None:
         scale = 1.0 / math.sqrt(128.0)
     ws, nbytes = None, 0
