@@ -82,14 +82,18 @@ def pmc_traffic_bytes(group):
     return None
 
 
-def vae_decode_rate(dev, z8):
-    """Wan2.2 VAE decode of one chunk (8 latents [48,8,44,80] -> 29 frames 704x1280), random-init weights:
-    the second half of BASELINE.json's metric ("VAE dec latents/s"). Not part of `value`."""
+def _rand_vae(dev, version):
     from yume_amd import synth
-    from yume_amd.wan23.modules.vae2_2 import Wan2_2_VAE, WanVAE_
-    cfg = synth.VAE_CFG_22
-    with torch.device(dev):
-        m = WanVAE_(dim=cfg["dim"], dec_dim=cfg["dec_dim"], z_dim=cfg["z_dim"], temperal_downsample=cfg["temperal_downsample"])
+    if version == "2.2":
+        from yume_amd.wan23.modules.vae2_2 import Wan2_2_VAE as Wrap, WanVAE_
+        cfg = synth.VAE_CFG_22
+        with torch.device(dev):
+            m = WanVAE_(dim=cfg["dim"], dec_dim=cfg["dec_dim"], z_dim=cfg["z_dim"], temperal_downsample=cfg["temperal_downsample"])
+    else:
+        from yume_amd.wan.modules.vae import WanVAE as Wrap, WanVAE_
+        cfg = synth.VAE_CFG_21
+        with torch.device(dev):
+            m = WanVAE_(dim=cfg["dim"], z_dim=cfg["z_dim"], temperal_downsample=cfg["temperal_downsample"])
     g = torch.Generator(device=dev).manual_seed(5)
     with torch.no_grad():
         for k, p in m.named_parameters():
@@ -99,16 +103,55 @@ def vae_decode_rate(dev, z8):
                 p.copy_(0.02 * torch.randn(p.shape, generator=g, device=dev))
             else:
                 p.copy_((torch.rand(p.shape, generator=g, device=dev) * 2 - 1) * (3.0 / p[0].numel()) ** 0.5)
-    vae = Wan2_2_VAE(device=dev, model=m)
-    vae.decode([z8])                                   # warm-up
+    return Wrap(device=dev, model=m)
+
+
+def _time_call(fn, reps=2):
+    fn()                                                # warm-up
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    out = vae.decode([z8])[0]
+    for _ in range(reps):
+        out = fn()
     torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    return (time.perf_counter() - t0) / reps, out
+
+
+def vae_decode_rate(dev, z8):
+    """Wan2.2 VAE decode of one chunk (8 latents [48,8,44,80] -> 29 frames 704x1280), random-init weights:
+    the second half of BASELINE.json's metric ("VAE dec latents/s"). Not part of `value`. r5: the other VAE passes of the two pipelines ride
+    along under `passes` with their own roofline fractions (FLOPs: SURVEY Appendix D / a17 — Wan2.2 17-frame encode 54.7 TFLOP, Wan2.1
+    decode of 13 latents 218.6, Wan2.1 49-frame encode 130.2; the 14B pipeline re-encodes its history every chunk)."""
+    vae = _rand_vae(dev, "2.2")
+    dt, out = _time_call(lambda: vae.decode([z8])[0], reps=1)
     assert torch.isfinite(out).all()
-    return {"latents_per_s": z8.shape[1] / dt, "ms_per_chunk": dt * 1e3, "chunk": "8 latents 48x8x44x80 -> 29 frames 704x1280",
-            "tflop_per_chunk": 485.04, "tflops": 485.04 / dt}
+    res = {"latents_per_s": z8.shape[1] / dt, "ms_per_chunk": dt * 1e3, "chunk": "8 latents 48x8x44x80 -> 29 frames 704x1280",
+           "tflop_per_chunk": 485.04, "tflops": 485.04 / dt, "frac": 485.04 / dt / MFMA_BF16_PEAK_TFLOPS}
+    passes = {}
+    g = torch.Generator(device=dev).manual_seed(6)
+
+    def add(name, fn, tflop, what, latents):
+        try:
+            d, o = _time_call(fn, reps=1)
+            assert torch.isfinite(o).all()
+            passes[name] = {"ms": d * 1e3, "tflop": tflop, "tflops": tflop / d, "frac": tflop / d / MFMA_BF16_PEAK_TFLOPS, "latents_per_s": latents / d,
+                            "what": what}
+        except Exception as e:  # noqa: BLE001 — a side measurement never hides the headline
+            passes[name] = {"failed": f"{type(e).__name__}: {e}"}
+    clip17 = torch.rand((3, 17, 704, 1280), generator=g, device=dev) * 2 - 1
+    add("wan22_encode_17_frames", lambda: vae.encode([clip17])[0], 54.7, "Wan2.2 encode 3x17x704x1280 -> 48x5x44x80 (vae2_2.py:797-829)", 5)
+    del vae, clip17
+    torch.cuda.empty_cache()
+    vae21 = _rand_vae(dev, "2.1")
+    z13 = torch.randn((16, 13, 68, 120), generator=g, device=dev)
+    add("wan21_decode_13_latents", lambda: vae21.decode([z13])[0], 218.6, "Wan2.1 decode 16x13x68x120 -> 3x49x544x960 (wan/modules/vae.py:544-568)", 13)
+    clip49 = torch.rand((3, 49, 544, 960), generator=g, device=dev) * 2 - 1
+    add("wan21_encode_49_frames", lambda: vae21.encode([clip49])[0], 130.2, "Wan2.1 encode 3x49x544x960 -> 16x13x68x120 (wan/modules/vae.py:516-542)", 13)
+    res["passes"] = passes
+    res["parity"] = ("every pass above is held to the fp32 device gold at exactly this size in tests/test_zy_vae_fullsize_gpu.py "
+                     "(rel-L2 1.1e-2 ... 1.3e-2 decode, 6e-3 ... 1.1e-2 encode; tolerance 3e-2)")
+    del vae21
+    torch.cuda.empty_cache()
+    return res
 
 
 def vae_cpu_baseline():
@@ -135,6 +178,18 @@ def vae_cpu_baseline():
     return {"value": (tf / dt) / (485.04 / 8.0), "unit": "latents/s", "cores": ncore, "host_threads": os.cpu_count(), "kind": "port",
             "sample": f"oracle decode of 2 latents 48x2x6x10 ({tf:.2f} TFLOP, {dt:.2f} s = {tf / dt:.2f} TFLOP/s fp32), "
                       "scaled by FLOPs to the 704x1280 chunk (60.6 TFLOP per latent)"}
+
+
+def port_vs_reference():
+    """cpu_baseline.kind is "port" on the GPU box (no reference tree there): how the port's time relates to the REAL reference module's on
+    the same host, measured in the build container by tools/port_vs_reference.py and committed (profiles/r5_cpu_port_vs_reference.json)."""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "r5_cpu_port_vs_reference.json")))
+        return {"reference_over_port": d["reference_over_port"], "reference_s": d["reference_s"], "port_s": d["port_s"], "threads": d["threads"],
+                "outputs_rel_l2": d["outputs_rel_l2"], "measured": "build container (the only place the reference tree exists), tools/port_vs_reference.py: "
+                + d["what"]}
+    except Exception as e:  # noqa: BLE001
+        return {"failed": str(e)}
 
 
 def block_flops_5b(L, cfg, Lc=512):
@@ -172,7 +227,8 @@ def cpu_baseline(cfg, L, model):
             "sample": f"1 of {cfg['num_layers']} DiT blocks at L={L} (fp32, {dt:.2f} s = {tf:.2f} TFLOP/s on {best} of {ncpu} host threads), "
                       f"extrapolated x{cfg['num_layers']}; embed/head excluded; thread sweep on an L={Ls} block (TFLOP/s): "
                       + ", ".join(f"{t}: {v:.2f}" for t, v in sweep.items())
-                      + "; kind 'port' = oracle/dit.py (restatement pinned to the reference): the GPU box has no reference tree to execute"}
+                      + "; kind 'port' = oracle/dit.py (restatement pinned to the reference): the GPU box has no reference tree to execute",
+            "port_vs_reference": port_vs_reference()}
     # device leg: block 0 of the benchmarked model temporarily holds the case's weights
     blk = model.blocks[0]
     saved = {k: v.detach().clone() for k, v in blk.state_dict().items()}
@@ -368,7 +424,9 @@ def bench_longvideo(args, rank, world, dev, built=None, emit=True):
                           "latents_per_s": world * args.chunks * lfz / dt, "final_history_latents": int(hist.shape[1]),
                           "weight_broadcast_collectives": n_bcast,
                           "model_tflop_timed": tf, "model_tflops_per_gpu": tf / dt, "parts_of_one_chunk": parts,
-                          "model_tflop_note": "DiT forwards of every chunk at its own L + 485.04 per chunk decode + 54.7 for the 17-frame encode"})
+                          "model_tflop_note": "DiT forwards of every chunk at its own L + 485.04 per chunk decode + 54.7 for the 17-frame encode",
+                          "read_as": f"a {args.steps}-step-per-chunk run of the configs[4] loop (the reference samples 50 steps per chunk: there the denoise "
+                                     "steps are 93 % of a chunk and the rate approaches the headline's); NOT configs[4]'s own number unless --steps 50"})
         if emit:
             print(json.dumps(res), flush=True)
     if world > 1 and emit:
@@ -442,7 +500,10 @@ def bench_14b(args, rank, world, dev, emit=True):
                           "config": {"workload": "Yume-I2V-14B-540P random-init, latent 16x17x68x120 + y, FramePack lfz=9, L=27810, CFG 5.0 "
                                                  "(2 forwards/step), 50-step shift-3 schedule", "num_layers": cfg["num_layers"], "tokens": L},
                           "model_tflop_per_step": tf, "model_tflops_per_gpu": tf / (ms * 1e-3),
-                          "peak_mem_gb": torch.cuda.max_memory_allocated() / 1e9})
+                          "peak_mem_gb": torch.cuda.max_memory_allocated() / 1e9,
+                          "parity": "this exact configuration (L = 27810, 40 blocks, CFG 5.0) is held to the fp32 device gold in "
+                                    "tests/test_zz_full_step_gpu.py::test_full_depth_14b_cfg_step_at_the_benchmarked_length_vs_device_gold "
+                                    "(cond 5.0e-3, uncond 4.8e-3, guided velocity 1.3e-2, updated latent 2.1e-4; tolerance 3e-2 / 4e-2 / 3e-3)"})
         if emit:
             print(json.dumps(res), flush=True)
     if world > 1 and emit:
@@ -456,7 +517,7 @@ def other_workloads(args, dev, built):
     import copy
     res = {}
     for name, fn, kw, ov in (("tts", bench_tts, {"built": built}, dict(steps=4, warmup=2)),
-                             ("longvideo", bench_longvideo, {"built": built}, dict(steps=2, warmup=1, chunks=8)),
+                             ("longvideo", bench_longvideo, {"built": built}, dict(steps=8, warmup=1, chunks=8)),
                              ("14b", bench_14b, {}, dict(steps=3, warmup=1))):
         a = copy.copy(args)
         for k, v in ov.items():
@@ -497,7 +558,8 @@ def full_step_parity(job, model, cfg):
             "sample": f"ONE WHOLE denoise step (30 blocks + embeddings + head at L=9460, fp32): {ref['seconds']:.1f} s = {tf / ref['seconds']:.2f} TFLOP/s on "
                       f"{ref['threads']} of {ref['host_threads']} host threads (+ {ref['gen_seconds']:.1f} s generating the weights, not counted), measured while "
                       "the GPU ran the side workloads; kind 'port' = oracle/dit.py (restatement pinned to the reference): the GPU box has no "
-                      "reference tree to execute"}
+                      "reference tree to execute",
+            "port_vs_reference": port_vs_reference()}
     return par, base
 
 
@@ -555,6 +617,9 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
+        # N ranks share one host: each keeps a small OpenMP / intra-op team (the engine's host side is small tensor ops; 8 ranks x torch's
+        # default of every hardware thread oversubscribes the box, and rank 0's CPU legs start only after the other ranks have left)
+        torch.set_num_threads(max(1, min(16, (os.cpu_count() or 8) // world)))
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if share:
             dist.init_process_group("gloo")              # collectives staged through the host (yume_amd.distributed)
@@ -644,6 +709,19 @@ def main():
         model.engine.prof = None
         del lat_x
     assert torch.isfinite(latent).all(), "non-finite latents"
+    # per-box calibration, right behind the timed steps (same thermal / power state): what this chip sustains under a pure MFMA load and
+    # on one fixed reference launch of the product GEMM (yume_amd/calibrate.py)
+    calib = None
+    if rank == 0:
+        try:
+            from yume_amd import calibrate
+            cm, cg = calibrate.mfma_sustained(dev), calibrate.gemm_reference(dev)
+            calib = {"mfma_sustained_tflops": cm["tflops"], "mfma_clock_ghz": cm["clock_ghz"], "s_memtime_ghz": cm["s_memtime_ghz"],
+                     "gemm_8192_tflops": cg["tflops"], "gemm_8192_ms": cg["ms_per_launch"], "kernel": cm["kernel"],
+                     "note": "measured in this process right behind the timed steps; frac_of_sustained = achieved / mfma_sustained_tflops "
+                             "(frac stays achieved / the nominal 2500 TFLOP/s = 2.4 GHz x 32 clocks per 32x32x16 MFMA x 4 SIMDs x 256 CUs)"}
+        except Exception as e:  # noqa: BLE001
+            calib = {"failed": f"{type(e).__name__}: {e}"}
     # results of every chain are gathered at chunk end (the only other collective of the run)
     checks = ydist.gather_scalars(float(latent[:, -lfz:].double().abs().mean()), device=_coll_dev(dev))
 
@@ -678,6 +756,10 @@ def main():
         rl_dom = kernel_rooflines(prof, args.steps, ms_per_step, L, cfg)           # the dominant group, inside the timed steps
         rl_rest = [r for r in kernel_rooflines(prof_all, n_extra, ms_per_step, L, cfg) if r["group"] != dominant]
         rl_all = rl_dom + rl_rest
+        if calib and calib.get("mfma_sustained_tflops"):
+            for r in rl_all:
+                if r.get("bound") == "mfma" and r.get("achieved"):
+                    r["frac_of_sustained"] = r["achieved"] / calib["mfma_sustained_tflops"]
         out = {
             "metric": "denoise-steps/sec (Yume-5B 720P, 33-frame latent)",
             "value": (1 if sp else world) * args.steps / tmax, "unit": "denoise-steps/sec",
@@ -687,6 +769,7 @@ def main():
                                    "lfz=8, L=9460), ODE Euler steps of a 50-step shift-7 schedule, no CFG, one chain per GPU",
                        "num_layers": cfg["num_layers"], "tokens": L, "parallelism": (f"sp{world} (one chain, Ulysses all-to-all, replicated weights)" if sp
                                        else f"dp{world} (independent chains, replicated weights)")},
+            "calibration": calib,
             "chain_checksums": checks, "weight_broadcast_collectives": n_bcast,
             "vae_decode": vae_res,
             "cached_context_ms_per_step": cached_ms,

@@ -38,7 +38,7 @@ extern "C" {
 /* ---- library info ------------------------------------------------------------------- */
 const char* yume_last_error(void);
 /* ABI version of this header; bumped on any signature change (yume_amd/_lib.py refuses a library that reports another one). */
-#define YUME_ABI_VERSION 6
+#define YUME_ABI_VERSION 7
 int yume_abi_version(void);
 /* name of the gfx target the kernels were compiled for ("gfx950"). */
 const char* yume_target_arch(void);
@@ -54,6 +54,14 @@ const char* yume_target_arch(void);
  * schedules (same results). The registration is per process and per device (the calling thread's current device). */
 int64_t yume_counter_workspace_bytes(void);
 int yume_counter_workspace_init(void* ptr, int64_t bytes, void* stream);
+
+/* ---- per-box calibration (r5; no reference counterpart — measurement plumbing of bench.py) ----------------
+ * Launches `workgroups` x 256 threads (one wave per SIMD), each wave issuing iters * 16 v_mfma_f32_32x32x16_bf16 (32768 flop each, 32
+ * matrix-pipe clocks each) and nothing else. The caller times the launch with events on `stream`: workgroups * 4 * iters * 16 * 32768
+ * flop / time = the dense bf16 rate THIS chip sustains under a pure matrix load (nominal 2.5 PFLOP/s assumes 2.4 GHz; the package power
+ * limit holds a loaded MI355X near 1.7-1.8 GHz, and by how much differs from box to box). ticks (optional): uint64 [workgroups][2] =
+ * {s_memtime delta, s_memrealtime delta (100 MHz)} of each workgroup's first wave; sink: 4 bytes of device memory (never written). */
+int yume_calibrate_mfma(int64_t iters, int64_t workgroups, void* ticks, void* sink, void* stream);
 
 /* ---- fused LayerNorm + modulate  ---------------------------------------------------------
  * replaces: wan23/modules/model.py:300-301,309-310 (norm1/norm2 + `*(1+scale)+shift`),

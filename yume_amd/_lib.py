@@ -20,6 +20,7 @@ SIGNATURES = {
     "yume_target_arch": [],
     "yume_counter_workspace_bytes": [],
     "yume_counter_workspace_init": [_P, _L, _P],
+    "yume_calibrate_mfma": [_L, _L, _P, _P, _P],
     "yume_adaln_modulate": [_P, _L, _L, _L, _F, _P, _P, _L, _P, _I, _P, _L, _I, _P],
     "yume_gemm_bf16": [_P, _L, _P, _L, _P, _L, _L, _L, _I, _P, _L, _P, _L, _P, _P, _L, _L, _I, _P],
     "yume_rmsnorm_f32": [_P, _L, _L, _L, _F, _P, _P, _L, _P],
@@ -54,7 +55,7 @@ _RES = {"yume_last_error": c_char_p, "yume_target_arch": c_char_p, "yume_gemm_sp
         "yume_counter_workspace_bytes": c_int64}
 
 _lib = None
-ABI_VERSION = 6          # must equal YUME_ABI_VERSION in include/yume_hip.h; bumped whenever an argument list changes
+ABI_VERSION = 7          # must equal YUME_ABI_VERSION in include/yume_hip.h; bumped whenever an argument list changes
 
 
 def load():

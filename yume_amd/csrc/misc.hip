@@ -321,3 +321,47 @@ extern "C" int yume_transpose_bf16(const void* in, int in_bf16, int64_t ldi, int
     YUME_CHECK_LAUNCH("transpose_bf16");
     return YUME_OK;
 }
+
+// ---- per-box calibration (bench.py): what THIS chip sustains under a pure matrix-pipe load ------------------------------------------
+// `workgroups` x 4 waves (one per SIMD, as the product kernels), each issuing iters x 16 v_mfma_f32_32x32x16_bf16 on two independent
+// accumulator sets and nothing else: 2 * 32 * 32 * 16 flop per instruction, 32 clocks of one SIMD's matrix pipe each. The caller times
+// the launch with events on `stream`; ticks[wg] = {s_memtime delta, s_memrealtime delta (100 MHz)} of the workgroup's first wave.
+// Identical MI355X boxes differ by several per cent in the clock their power management sustains under such a load: the
+// bench line carries this figure so that its rates can be compared across boxes.
+namespace {
+__global__ __launch_bounds__(256) void calibrate_mfma_kernel(long long iters, unsigned long long* ticks, float* sink) {
+    f32x16 a0 = {}, a1 = {};
+    bf16x8_t x, y;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        x[i] = (__bf16)(0.001f * (float)((threadIdx.x + i) & 31));
+        y[i] = (__bf16)(0.002f * (float)((threadIdx.x - i) & 15));
+    }
+    const unsigned long long c0 = __builtin_readcyclecounter(), r0 = __builtin_amdgcn_s_memrealtime();
+    for (long long it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x, y, a0, 0, 0, 0);
+            a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x, y, a1, 0, 0, 0);
+        }
+    }
+    const unsigned long long c1 = __builtin_readcyclecounter(), r1 = __builtin_amdgcn_s_memrealtime();
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s += a0[i] + a1[i];
+    if (s == 12345.678f) sink[0] = s;                 // keeps the accumulators alive; never true
+    if (threadIdx.x == 0 && ticks) {
+        ticks[2 * blockIdx.x] = c1 - c0;
+        ticks[2 * blockIdx.x + 1] = r1 - r0;
+    }
+}
+}  // namespace
+
+extern "C" int yume_calibrate_mfma(int64_t iters, int64_t workgroups, void* ticks, void* sink, void* stream) {
+    YUME_REQUIRE(iters > 0 && workgroups > 0 && workgroups <= 65535, "calibrate_mfma: iters / workgroups out of range");
+    YUME_REQUIRE(sink != nullptr, "calibrate_mfma: sink must point at 4 bytes of device memory");
+    hipLaunchKernelGGL(calibrate_mfma_kernel, dim3((unsigned)workgroups), dim3(256), 0, (hipStream_t)stream, (long long)iters,
+                       (unsigned long long*)ticks, (float*)sink);
+    YUME_CHECK_LAUNCH("calibrate_mfma");
+    return YUME_OK;
+}
