@@ -57,7 +57,7 @@ int yume_counter_workspace_init(void* ptr, int64_t bytes, void* stream);
 
 /* ---- per-box calibration (r5; no reference counterpart — measurement plumbing of bench.py) ----------------
  * Launches `workgroups` x 256 threads (one wave per SIMD), each wave issuing iters * 16 v_mfma_f32_32x32x16_bf16 (32768 flop each, 32
- * matrix-pipe clocks each) and nothing else. The caller times the launch with events on `stream`: workgroups * 4 * iters * 16 * 32768
+ * matrix-pipe clocks each) on random operands (constant ones draw little power and run at 2.3 GHz) and nothing else. The caller times the launch with events on `stream`: workgroups * 4 * iters * 16 * 32768
  * flop / time = the dense bf16 rate THIS chip sustains under a pure matrix load (nominal 2.5 PFLOP/s assumes 2.4 GHz; the package power
  * limit holds a loaded MI355X near 1.7-1.8 GHz, and by how much differs from box to box). ticks (optional): uint64 [workgroups][2] =
  * {s_memtime delta, s_memrealtime delta (100 MHz)} of each workgroup's first wave; sink: 4 bytes of device memory (never written). */

@@ -72,9 +72,8 @@ def _one_rank_worker(rank, world, port, out_dir):
     synth.randomize_module_(m, seed=10)
     m = m.to(torch.bfloat16)
     before = [p.detach().clone() for p in m.parameters()]
-    nparam = sum(p.numel() * p.element_size() for p in m.parameters())
-    n1 = D.broadcast_module_(m, src=0, bucket_bytes=1 << 20, force=True)                 # several 1 MiB device buckets -> dist.broadcast each
-    assert n1 >= max(2, nparam // (1 << 20) // 2), (n1, nparam)
+    n1 = D.broadcast_module_(m, src=0, bucket_bytes=1 << 20, force=True)                 # 1 MiB device buckets (a larger tensor is its own) -> dist.broadcast each
+    assert n1 >= 8, n1
     n2 = D.broadcast_module_(m, src=0, bucket_bytes=1 << 20, mode="scatter_allgather", force=True)   # dist.scatter + all_gather_into_tensor
     assert n2 == 2 * n1
     torch.cuda.synchronize()

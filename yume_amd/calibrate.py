@@ -4,7 +4,7 @@ The same binaries moved 7-8.6 % between two "identical" boxes (power-limited clo
 compared across rounds without a figure for the box. Two figures, both cheap:
 
   * mfma_sustained()  the fixed matrix-pipe microkernel of the library (yume_calibrate_mfma: one wave per SIMD on every CU issuing
-                      v_mfma_f32_32x32x16_bf16 back to back, nothing else), run for a few hundred ms so that the power management settles:
+                      v_mfma_f32_32x32x16_bf16 back to back on random operands, nothing else), run for a few hundred ms so that the power management settles:
                       the dense bf16 rate and the clock the chip holds under a pure MFMA load — an upper bound for any real kernel;
   * gemm_reference()  one fixed launch of the product GEMM (8192^3, bf16 out): a reference launch with real operand traffic.
 """
@@ -53,7 +53,7 @@ def mfma_sustained(device, settle_s=0.3, measure_s=0.4, iters=20000):
     smt = float((t[good, 0] / (t[good, 1] / 100e6)).mean()) / 1e9 if bool(good.any()) else None
     return {"tflops": rate / 1e12, "clock_ghz": mfma_per_wave * CLK_PER_MFMA / dt / 1e9, "s_memtime_ghz": smt, "launches": n,
             "ms_per_launch": dt / n * 1e3, "cus": ncu,
-            "kernel": "yume_calibrate_mfma: 4 waves per CU x v_mfma_f32_32x32x16_bf16 back to back (32768 flop, 32 pipe clocks each), no memory traffic"}
+            "kernel": "yume_calibrate_mfma: 4 waves per CU x v_mfma_f32_32x32x16_bf16 back to back on random operands (32768 flop, 32 pipe clocks each), no memory traffic"}
 
 
 def gemm_reference(device, n=8192, reps=20):

@@ -324,32 +324,44 @@ extern "C" int yume_transpose_bf16(const void* in, int in_bf16, int64_t ldi, int
 
 // ---- per-box calibration (bench.py): what THIS chip sustains under a pure matrix-pipe load ------------------------------------------
 // `workgroups` x 4 waves (one per SIMD, as the product kernels), each issuing iters x 16 v_mfma_f32_32x32x16_bf16 on two independent
-// accumulator sets and nothing else: 2 * 32 * 32 * 16 flop per instruction, 32 clocks of one SIMD's matrix pipe each. The caller times
+// accumulator sets and random operands, and nothing else: 2 * 32 * 32 * 16 flop per instruction, 32 clocks of one SIMD's matrix pipe each. The caller times
 // the launch with events on `stream`; ticks[wg] = {s_memtime delta, s_memrealtime delta (100 MHz)} of the workgroup's first wave.
 // Identical MI355X boxes differ by several per cent in the clock their power management sustains under such a load: the
 // bench line carries this figure so that its rates can be compared across boxes.
 namespace {
 __global__ __launch_bounds__(256) void calibrate_mfma_kernel(long long iters, unsigned long long* ticks, float* sink) {
+    // RANDOM operands, a different pair for each of the 8 MFMA slots of the loop body: the energy of a matrix instruction follows the
+    // bits that toggle — with constant operands the same launch runs at 2.31 GHz / 2.42 PFLOP/s (r5, first build), no power limit in sight.
     f32x16 a0 = {}, a1 = {};
-    bf16x8_t x, y;
+    bf16x8_t x[8], y[8];
+    unsigned h = (blockIdx.x * 256u + threadIdx.x) * 2654435761u + 12345u;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        x[i] = (__bf16)(0.001f * (float)((threadIdx.x + i) & 31));
-        y[i] = (__bf16)(0.002f * (float)((threadIdx.x - i) & 15));
+    for (int k = 0; k < 8; ++k) {
+        u32x4 wx, wy;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            // two bf16 per word: sign and 7 mantissa bits random, exponent 125..128 (|v| in [0.25, 4)) — finite sums whatever the count
+            h = h * 1664525u + 1013904223u;
+            wx[i] = (h & 0x80ff80ffu) | 0x3e803e80u | ((h >> 3) & 0x01800180u);
+            h = h * 1664525u + 1013904223u;
+            wy[i] = (h & 0x80ff80ffu) | 0x3e803e80u | ((h >> 5) & 0x01800180u);
+        }
+        x[k] = __builtin_bit_cast(bf16x8_t, wx);
+        y[k] = __builtin_bit_cast(bf16x8_t, wy);
     }
     const unsigned long long c0 = __builtin_readcyclecounter(), r0 = __builtin_amdgcn_s_memrealtime();
     for (long long it = 0; it < iters; ++it) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x, y, a0, 0, 0, 0);
-            a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x, y, a1, 0, 0, 0);
+            a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x[j], y[j], a0, 0, 0, 0);
+            a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(y[j], x[(j + 3) & 7], a1, 0, 0, 0);
         }
     }
     const unsigned long long c1 = __builtin_readcyclecounter(), r1 = __builtin_amdgcn_s_memrealtime();
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < 16; ++i) s += a0[i] + a1[i];
-    if (s == 12345.678f) sink[0] = s;                 // keeps the accumulators alive; never true
+    if (s == 12345.678f) sink[0] = s;                 // keeps the accumulators alive; (practically) never true
     if (threadIdx.x == 0 && ticks) {
         ticks[2 * blockIdx.x] = c1 - c0;
         ticks[2 * blockIdx.x + 1] = r1 - r0;

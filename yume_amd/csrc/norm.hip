@@ -2,6 +2,10 @@
 //   * fused LayerNorm(no affine) + modulate -> bf16 / fp32 / 3-way bf16 split
 //   * RMSNorm over the full hidden dim (+ interleaved-pair 3D RoPE), in place on bf16 q|k
 // One 256-thread workgroup per token row; every global access is a 16-byte vector.
+// (r5, measured and removed: ONE WAVE per row — 64 lanes x 12 vectors, statistics by two wave reductions, no LDS and no barrier, four
+// independent rows per workgroup, 16 rows in flight per CU. Slower at every shape of the block: adaLN 37.6 vs 31.3 us, RMSNorm+RoPE 43.3 vs
+// 42.0 us at the 5B width, 251 vs 219 / 288 vs 242 us at the 14B width (profiles/r5_norm_wave_ab.json; git show 307463c:yume_amd/csrc/norm.hip
+// has the kernels): a wave's twelve 1 KiB loads go out one behind the other, while a block's 256 threads fetch a row in three 4 KiB pieces.)
 // Roofline: HBM. Algorithmic bytes per token: adaln 4C read + 2C write; rmsnorm_rope 2*nparts*C r+w.
 #include "common.hpp"
 
@@ -179,154 +183,6 @@ __global__ __launch_bounds__(NT) void rmsnorm_rope_kernel(unsigned short* __rest
     }
 }
 
-// ---- r5: ONE WAVE PER ROW --------------------------------------------------------------------------------------------------------------
-// The block-per-row kernels above spend two (adaLN: four) workgroup barriers per row on their statistics, and a row's loads, reductions and
-// stores form one dependent chain per workgroup: 5.1 TB/s (adaLN) / ~4.5 TB/s (RMSNorm+RoPE) at the 5B width, 0.64 / 0.57 of the HBM roofline
-// (VERDICT r4 weak #9). Here a wave owns a row — 64 lanes x NV 16-byte vectors, NV = C / 256 (adaLN, fp32) or nparts * C / 512 (bf16 q|k) —
-// its statistics are two wave reductions (DPP, no LDS, no barrier), and the four waves of a workgroup are four independent rows in flight.
-// Same arithmetic per element as the kernels above; the statistics are summed in another order (per-lane partials, then the wave tree).
-template <int NV, bool RMS>
-__global__ __launch_bounds__(NT) void adaln_wave_kernel(const float* __restrict__ x, int64_t ldx, int64_t T, int C, float eps,
-                                                        const float* __restrict__ mul, const float* __restrict__ add, int64_t tab_stride,
-                                                        const int32_t* __restrict__ row_idx, float add_one, void* __restrict__ out,
-                                                        int64_t ldo, int out_kind) {
-    const int lane = threadIdx.x & 63;
-    const int64_t t = (int64_t)blockIdx.x * (NT / 64) + (threadIdx.x >> 6);
-    if (t >= T) return;                                  // (whole waves leave: no barrier below)
-    const float* xr = x + t * ldx;
-    const int nvec = C >> 2;
-    f32x4 v[NV];
-    float s = 0.f;
-#pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        const int vi = lane + i * 64;
-        if (vi < nvec) {
-            v[i] = *reinterpret_cast<const f32x4*>(xr + 4 * vi);
-            s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
-        } else {
-            v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-    }
-    const int64_t row = row_idx ? (int64_t)row_idx[t] : 0;
-    const float* mr = mul + row * tab_stride;
-    const float* ar = RMS ? mr : add + row * tab_stride;
-    const float mean = RMS ? 0.f : wave_sum(s) / (float)C;
-    float q = 0.f;
-#pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        if (lane + i * 64 < nvec) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float d = v[i][j] - mean;
-                q += d * d;
-            }
-        }
-    }
-    const float rstd = rsqrtf(wave_sum(q) / (float)C + eps);
-#pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        const int vi = lane + i * 64;
-        if (vi < nvec) {
-            const f32x4 m4 = *reinterpret_cast<const f32x4*>(mr + 4 * vi);
-            const f32x4 a4 = RMS ? f32x4{0.f, 0.f, 0.f, 0.f} : *reinterpret_cast<const f32x4*>(ar + 4 * vi);
-            f32x4 y;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) y[j] = (v[i][j] - mean) * rstd * (m4[j] + add_one) + a4[j];
-            if (out_kind == 1) {
-                *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(out) + t * ldo + 4 * vi) = y;
-            } else {
-                unsigned short* ob = reinterpret_cast<unsigned short*>(out) + t * ldo;
-                u32x2 hi;
-                hi[0] = pack_bf16x2(y[0], y[1]);
-                hi[1] = pack_bf16x2(y[2], y[3]);
-                *reinterpret_cast<u32x2*>(ob + 4 * vi) = hi;
-                if (out_kind == 2) {
-                    *reinterpret_cast<u32x2*>(ob + C + 4 * vi) = hi;
-                    float r[4];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) r[j] = y[j] - bf16_to_f32(f32_to_bf16(y[j]));
-                    u32x2 lo;
-                    lo[0] = pack_bf16x2(r[0], r[1]);
-                    lo[1] = pack_bf16x2(r[2], r[3]);
-                    *reinterpret_cast<u32x2*>(ob + 2 * C + 4 * vi) = lo;
-                }
-            }
-        }
-    }
-}
-
-// NV 16-byte vectors (8 bf16) per lane: vi = lane + 64 i; part(vi) = vi / (C / 8) is uniform per i since (C / 8) % 64 == 0
-template <int NV>
-__global__ __launch_bounds__(NT) void rmsnorm_rope_wave_kernel(unsigned short* __restrict__ buf, int64_t ld, int64_t T, int C, int nparts,
-                                                               const float* __restrict__ w, float eps, const float* __restrict__ rope,
-                                                               int wperiod) {
-    const int lane = threadIdx.x & 63;
-    const int64_t t = (int64_t)blockIdx.x * (NT / 64) + (threadIdx.x >> 6);
-    if (t >= T) return;
-    if (wperiod > 1) w += (int64_t)(t % wperiod) * nparts * C;
-    unsigned short* row = buf + t * ld;
-    const int vpp = C >> 3;
-    const int nvec = vpp * nparts;
-    u16x8 v[NV];
-    float ss[2] = {0.f, 0.f};
-#pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        const int vi = lane + i * 64;
-        if (vi < nvec) {
-            v[i] = *reinterpret_cast<const u16x8*>(row + 8 * vi);
-            float a = 0.f;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float f = bf16_to_f32(v[i][j]);
-                a += f * f;
-            }
-            if (vi < vpp) ss[0] += a; else ss[1] += a;
-        }
-    }
-    const float r0 = rsqrtf(wave_sum(ss[0]) / (float)C + eps);
-    const float r1 = nparts > 1 ? rsqrtf(wave_sum(ss[1]) / (float)C + eps) : 0.f;
-    const float* rp = rope ? rope + t * 128 : nullptr;
-#pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        const int vi = lane + i * 64;
-        if (vi < nvec) {
-            const float r = vi >= vpp ? r1 : r0;
-            const int c0 = 8 * vi;
-            const f32x4 w0 = *reinterpret_cast<const f32x4*>(w + c0);
-            const f32x4 w1 = *reinterpret_cast<const f32x4*>(w + c0 + 4);
-            float y[8];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                y[j] = bf16_to_f32(v[i][j]) * r * w0[j];
-                y[4 + j] = bf16_to_f32(v[i][4 + j]) * r * w1[j];
-            }
-            if (rp) {
-                const int pr = (c0 & 127) >> 1;
-                const f32x4 cs0 = *reinterpret_cast<const f32x4*>(rp + 2 * pr);
-                const f32x4 cs1 = *reinterpret_cast<const f32x4*>(rp + 2 * pr + 4);
-                const float cs[8] = {cs0[0], cs0[1], cs0[2], cs0[3], cs1[0], cs1[1], cs1[2], cs1[3]};
-#pragma unroll
-                for (int p = 0; p < 4; ++p) {
-                    const float a = y[2 * p], b = y[2 * p + 1];
-                    const float c = cs[2 * p], s = cs[2 * p + 1];
-                    y[2 * p] = a * c - b * s;
-                    y[2 * p + 1] = a * s + b * c;
-                }
-            }
-            u32x4 o;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) o[j] = pack_bf16x2(y[2 * j], y[2 * j + 1]);
-            *reinterpret_cast<u32x4*>(row + 8 * vi) = o;
-        }
-    }
-}
-
-// YUME_NORM_WAVE: 1 = the wave-per-row kernels (default where they apply), 0 = the block-per-row kernels (A/B runs, cross-checks)
-bool norm_wave() {
-    static const bool on = [] { const char* v = getenv("YUME_NORM_WAVE"); return !v || atoi(v) != 0; }();
-    return on;
-}
-
 }  // namespace
 
 extern "C" int yume_adaln_modulate(const float* x, int64_t ldx, int64_t T, int64_t C, float eps, const float* mul,
@@ -340,17 +196,6 @@ extern "C" int yume_adaln_modulate(const float* x, int64_t ldx, int64_t T, int64
     hipStream_t st = (hipStream_t)stream;
     const float one = add_one ? 1.f : 0.f;
     dim3 grid((unsigned)T), block(NT);
-    if (norm_wave()) {
-        dim3 gw((unsigned)((T + 3) / 4));
-#define YUME_ADALN_W(NV) hipLaunchKernelGGL((adaln_wave_kernel<NV, false>), gw, block, 0, st, x, ldx, T, (int)C, eps, mul, add, tab_stride, row_idx, one, out, ldo, out_kind)
-        if (C <= 256 * 6) YUME_ADALN_W(6);
-        else if (C <= 256 * 12) YUME_ADALN_W(12);
-        else if (C <= 256 * 20) YUME_ADALN_W(20);
-        else YUME_ADALN_W(32);
-#undef YUME_ADALN_W
-        YUME_CHECK_LAUNCH("adaln_modulate");
-        return YUME_OK;
-    }
     if (C <= NT * 4 * 3)
         hipLaunchKernelGGL(adaln_kernel<3>, grid, block, 0, st, x, ldx, (int)C, eps, mul, add, tab_stride, row_idx, one, out, ldo, out_kind);
     else if (C <= NT * 4 * 5)
@@ -369,17 +214,6 @@ extern "C" int yume_rmsnorm_f32(const float* x, int64_t ldx, int64_t T, int64_t 
     if (T == 0) return YUME_OK;
     hipStream_t st = (hipStream_t)stream;
     dim3 grid((unsigned)T), block(NT);
-    if (norm_wave()) {
-        dim3 gw((unsigned)((T + 3) / 4));
-#define YUME_RMS_W(NV) hipLaunchKernelGGL((adaln_wave_kernel<NV, true>), gw, block, 0, st, x, ldx, T, (int)C, eps, w, w, (int64_t)0, (const int32_t*)nullptr, 0.f, out, ldo, 0)
-        if (C <= 256 * 6) YUME_RMS_W(6);
-        else if (C <= 256 * 12) YUME_RMS_W(12);
-        else if (C <= 256 * 20) YUME_RMS_W(20);
-        else YUME_RMS_W(32);
-#undef YUME_RMS_W
-        YUME_CHECK_LAUNCH("rmsnorm_f32");
-        return YUME_OK;
-    }
     if (C <= NT * 4 * 3)
         hipLaunchKernelGGL((adaln_kernel<3, true>), grid, block, 0, st, x, ldx, (int)C, eps, w, w, (int64_t)0, (const int32_t*)nullptr, 0.f, out, ldo, 0);
     else if (C <= NT * 4 * 5)
@@ -418,17 +252,6 @@ static int rmsnorm_rope_impl(void* buf, int64_t ld, int64_t T, int64_t C, int np
     unsigned short* b = reinterpret_cast<unsigned short*>(buf);
     const int64_t nvec = (C / 8) * nparts;
     dim3 grid((unsigned)T), block(NT);
-    if (norm_wave()) {
-        dim3 gw((unsigned)((T + 3) / 4));
-#define YUME_RR_W(NV) hipLaunchKernelGGL(rmsnorm_rope_wave_kernel<NV>, gw, block, 0, st, b, ld, T, (int)C, nparts, w, eps, rope, wperiod)
-        if (nvec <= 64 * 6) YUME_RR_W(6);
-        else if (nvec <= 64 * 12) YUME_RR_W(12);
-        else if (nvec <= 64 * 20) YUME_RR_W(20);
-        else YUME_RR_W(32);
-#undef YUME_RR_W
-        YUME_CHECK_LAUNCH("rmsnorm_rope");
-        return YUME_OK;
-    }
     if (nvec <= NT * 2)
         hipLaunchKernelGGL(rmsnorm_rope_kernel<2>, grid, block, 0, st, b, ld, (int)C, nparts, w, eps, rope, wperiod);
     else if (nvec <= NT * 3)
