@@ -14,8 +14,9 @@ for b in range(len(w) // 8):
     if s[0] == 0 or s[2] == 0 or s[6] == 0:
         continue
     rows.append(s)
+# (stamp 2 = the top of an item that is not the workgroup's first: 2 -> 3 is that item's tiles up to the one before its last)
 print(len(rows), "workgroups with a complete item boundary")
-names = [("tile before last", 3, 4), ("bubble 1 (Q' + ticket)", 4, 5), ("boundary tile", 5, 6), ("range vote", 6, 1), ("O^T store + drain", 1, 2)]
+names = [("item start -> tile before last", 2, 3), ("tile before last", 3, 4), ("bubble 1 (Q' + ticket)", 4, 5), ("boundary tile", 5, 6), ("range vote", 6, 1), ("O^T store + drain", 1, 2)]
 for name, a, b in names:
     d = sorted((r[b] - r[a]) * 0.01 for r in rows if r[b] > r[a])
     if d:
