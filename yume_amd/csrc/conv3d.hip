@@ -264,8 +264,18 @@ extern "C" int yume_conv3d_cl(const void* x, const void* cache, int64_t ldc, int
         Problem p2 = p;
         p2.tiles_m = (int)((M + 255) / 256);
         p2.tiles_n = (int)((Cout + 255) / 256);
-        if (big && gemm_w4::conv_w4_applies(p2, cv, st, sh, sw, ups, e2) && (epi != YUME_CONV_EPI_ADD || (add != nullptr && (ldadd % 4) == 0)))
+        // (r5, measured and not kept: launches too small to fill the chip — the first-chunk passes, 56 tiles with K = 27 x 1024 — on this
+        // pipeline instead of the 128x128 kernel: decode 386.4-387.9 vs 387.3-388.2 ms, both K loops run at memory latency there;
+        // profiles/r5_vae_small_launch_ab.log. YUME_CONV_LOG=1 prints the kernel every call takes.)
+        if (big && gemm_w4::conv_w4_applies(p2, cv, st, sh, sw, ups, e2) && (epi != YUME_CONV_EPI_ADD || (add != nullptr && (ldadd % 4) == 0))) {
+            static const bool log_on = [] { const char* v = getenv("YUME_CONV_LOG"); return v && atoi(v) != 0; }();
+            if (log_on) fprintf(stderr, "[conv3d_cl] w4   M=%lld Cin=%lld Cout=%lld k=%dx%dx%d ups=%d tiles=%d\n", (long long)M, (long long)Cin, (long long)Cout, kt, kh, kw, (int)ups, p2.tiles_m * p2.tiles_n);
             return gemm_w4::launch_conv_w4(e2, p, cv, e, s, "conv3d_cl");
+        }
+        {
+            static const bool log_on = [] { const char* v = getenv("YUME_CONV_LOG"); return v && atoi(v) != 0; }();
+            if (log_on) fprintf(stderr, "[conv3d_cl] %s M=%lld Cin=%lld Cout=%lld k=%dx%dx%d stride=%d,%d,%d ups=%d\n", big ? "g256" : "g128", (long long)M, (long long)Cin, (long long)Cout, kt, kh, kw, st, sh, sw, (int)ups);
+        }
     }
     if ((Cin % BK) == 0 && !ups && kh * kw <= 32) {
         ConvAFast af = {};
