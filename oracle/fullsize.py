@@ -46,8 +46,18 @@ def make_block_case(cfg, family, L, seed=0, n_text=512):
     return dict(cfg=c1, family=family, sd=sd, x=x, e6=e6, rope=rope, ctx=ctx, L=L)
 
 
-def run_block_oracle(case):
-    """-> (x_out fp32 [L, C], seconds) on the host cores."""
+def run_block_oracle(case, device=None):
+    """-> (x_out fp32 [L, C] on the host, seconds). device None: on the host cores; "cuda": the same oracle.dit.block_forward on the GPU in
+    fp32 (oracle/devgold.py — for the 14B block at L = 27810, 90 s of host time otherwise)."""
+    if device is not None:
+        from . import devgold
+        dev = torch.device(device)
+        sd = {k: v.to(dev) for k, v in case["sd"].items()}
+        with torch.no_grad(), devgold.on_device(dev):
+            t0 = time.time()
+            y = odit.block_forward(sd, "blocks.0.", case["x"].to(dev), case["e6"].to(dev), case["rope"].to(dev), case["ctx"].to(dev),
+                                   case["cfg"], case["family"]).cpu()
+        return y, time.time() - t0
     orig = odit.attention
     odit.attention = attention_fp32
     try:

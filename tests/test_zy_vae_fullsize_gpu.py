@@ -59,7 +59,7 @@ def _frames(got, want):
 @pytest.mark.parametrize("version,zshape", [("2.2", (48, 1, 44, 80)), ("2.1", (16, 1, 68, 120))])
 def test_device_gold_reproduces_the_cpu_oracle_first_latent_decode(version, zshape):
     """the proof of the device gold for each decoder: full resolution, one latent (the CPU oracle's affordable size)."""
-    cfg, sd, _ = _vae(version, 31)
+    cfg, sd, vae = _vae(version, 31)
     z = torch.randn(*zshape, generator=torch.Generator().manual_seed(32))
     torch.set_num_threads(min(32, torch.get_num_threads()))
     t0 = time.time()
@@ -71,6 +71,12 @@ def test_device_gold_reproduces_the_cpu_oracle_first_latent_decode(version, zsha
     print(f"Wan{version} first-latent decode {tuple(want.shape)}: device gold vs CPU oracle rel-L2 {r:.3e} max-abs {(gold - want).abs().max():.3e}; "
           f"CPU {cpu_s:.1f} s, device gold {time.time() - t0:.1f} s")
     assert gold.shape == want.shape and r <= 1e-5
+    # the product path against the CPU oracle itself at this size (the r2 full-resolution first-latent test, 20.6 TFLOP for Wan2.2)
+    got = vae.decode([z.to(DEV)])[0].cpu()
+    rd = devgold.rel_l2(got, want)
+    print(f"Wan{version} first-latent decode: device (bf16) vs CPU oracle rel-L2 {rd:.3e} max-abs {(got - want).abs().max():.3e}")
+    assert got.shape == want.shape and torch.isfinite(got).all() and got.abs().max() <= 1.0
+    assert rd <= 3e-2
 
 
 def test_device_gold_reproduces_the_cpu_oracle_five_frame_encode():
