@@ -528,3 +528,15 @@ def test_gemm_small_m_split_k_matches_plain(M, N, K):
     ref = gemm_ref(a.cpu(), w.cpu(), bias.cpu())
     o32 = ops.gemm_small_m(a, w, bias, torch.empty(M, N, dtype=torch.float32, device=DEV), ops.EPI_F32)
     assert (o32.cpu().double() - ref).abs().max() < 1e-4 * max(1.0, ref.abs().max().item())
+
+
+def test_calibration_microkernel_reports_a_plausible_sustained_rate():
+    """yume_calibrate_mfma through yume_amd.calibrate (bench.py's `calibration`): the pure-MFMA rate on random operands must lie between a
+    tenth of and a little above the nominal 2.5 PFLOP/s, the implied clock and the kernel's own s_memtime reading must agree, and the fixed
+    8192^3 reference launch must land where the product GEMM does."""
+    from yume_amd import calibrate
+    m = calibrate.mfma_sustained(DEV, settle_s=0.05, measure_s=0.1)
+    assert 250.0 < m["tflops"] < 2700.0 and 0.25 < m["clock_ghz"] < 2.6
+    assert m["s_memtime_ghz"] is None or abs(m["s_memtime_ghz"] - m["clock_ghz"]) < 0.25 * m["clock_ghz"]
+    g = calibrate.gemm_reference(DEV, reps=5)
+    assert 300.0 < g["tflops"] < 2500.0
