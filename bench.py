@@ -20,7 +20,10 @@ The JSON line also carries
   cpu_baseline : the CPU oracle restatement of the reference (oracle/dit.py) timed on the host cores on a bounded
                  sample (one DiT block at the full L, extrapolated to 30 blocks), rank 0 / N=1 only.
   parity       : that same CPU block output against the device engine on identical inputs (rel-L2 / max-abs).
-  vae_decode   : Wan2.2 decode latents/s on the GPU and the oracle VAE on the host cores (reduced size, FLOP-scaled).
+  vae_decode   : Wan2.2 decode latents/s on the GPU and the oracle VAE on the host cores (reduced size, FLOP-scaled); `passes`: the other
+                 VAE passes of the two pipelines (Wan2.2 17-frame encode, Wan2.1 decode / encode) with their own roofline fractions.
+  calibration  : what THIS box sustains, measured right behind the timed steps (yume_amd/calibrate.py: pure-MFMA microkernel on random
+                 operands + one fixed 8192^3 launch of the product GEMM); every MFMA-bound group carries frac_of_sustained next to frac.
 
 --workload tts / longvideo / 14b run BASELINE.json configs[3] / [4] / [2] (see their functions); the default is configs[1].
 """

@@ -1,10 +1,9 @@
 #!/usr/bin/env python3
-"""Timing of the HBM-bound row kernels (adaLN, RMSNorm+RoPE) at the block's shapes; run once per YUME_NORM_WAVE setting (the library reads
-the switch once per process):
+"""Timing of the HBM-bound row kernels (adaLN, RMSNorm+RoPE) at the block's shapes, back-to-back launches. A/B of library builds:
+YUME_HIP_LIB=yume_amd/lib/exp/libyume_hip_<tag>.so python tools/norm_probe.py (r5 used it for the wave-per-row kernels of commit 307463c:
+profiles/r5_norm_wave_ab.json).
 
-    YUME_NORM_WAVE=0 python tools/norm_probe.py; YUME_NORM_WAVE=1 python tools/norm_probe.py
-
-Prints one JSON line: per case the average launch time over back-to-back launches, the algorithmic bytes and the achieved GB/s."""
+Prints one JSON line: per case the average launch time, and the achieved GB/s on the algorithmic bytes."""
 import json
 import os
 import sys
@@ -32,7 +31,7 @@ def timeit(fn, reps=200):
 
 def main():
     g = torch.Generator(device=DEV).manual_seed(1)
-    out = {"YUME_NORM_WAVE": os.environ.get("YUME_NORM_WAVE", "(default)")}
+    out = {"lib": os.environ.get("YUME_HIP_LIB", "product")}
     for name, L, C in (("5b", 9460, 3072), ("14b", 27810, 5120)):
         x = torch.randn((L, C), generator=g, device=DEV)
         tab = torch.randn((2, 6, C), generator=g, device=DEV) * 0.1
