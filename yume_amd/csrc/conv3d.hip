@@ -267,7 +267,11 @@ extern "C" int yume_conv3d_cl(const void* x, const void* cache, int64_t ldc, int
         // (r5, measured and not kept: launches too small to fill the chip — the first-chunk passes, 56 tiles with K = 27 x 1024 — on this
         // pipeline instead of the 128x128 kernel: decode 386.4-387.9 vs 387.3-388.2 ms, both K loops run at memory latency there;
         // profiles/r5_vae_small_launch_ab.log. YUME_CONV_LOG=1 prints the kernel every call takes.)
-        if (big && gemm_w4::conv_w4_applies(p2, cv, st, sh, sw, ups, e2) && (epi != YUME_CONV_EPI_ADD || (add != nullptr && (ldadd % 4) == 0))) {
+        // (N = 384 / 320 / 640 channels: 75 / 62 / 83 % of their 256-wide N tiles is real work, and the pipeline is worth 2x the gathering
+        // 128^2 kernel per padded flop — YUME_CONV_W4_WORTH overrides the 2.0 for A/B runs, 1.25 = the r4 rule)
+        static const double w4_worth = [] { const char* v = getenv("YUME_CONV_W4_WORTH"); const double d = v ? atof(v) : 2.0; return d > 0.5 ? d : 2.0; }();
+        const bool big_w4 = big || use_256(p, variant, true, w4_worth);
+        if (big_w4 && gemm_w4::conv_w4_applies(p2, cv, st, sh, sw, ups, e2) && (epi != YUME_CONV_EPI_ADD || (add != nullptr && (ldadd % 4) == 0))) {
             static const bool log_on = [] { const char* v = getenv("YUME_CONV_LOG"); return v && atoi(v) != 0; }();
             if (log_on) fprintf(stderr, "[conv3d_cl] w4   M=%lld Cin=%lld Cout=%lld k=%dx%dx%d ups=%d tiles=%d\n", (long long)M, (long long)Cin, (long long)Cout, kt, kh, kw, (int)ups, p2.tiles_m * p2.tiles_n);
             return gemm_w4::launch_conv_w4(e2, p, cv, e, s, "conv3d_cl");

@@ -833,14 +833,17 @@ int launch256(const Problem& p128, const ALoad& al, const Epilogue& e, hipStream
 }
 
 // kernel selection: variant 1 = 128^2 tile, 2 = 256^2 tile, 0 = automatic (256^2 once it fills the chip)
-inline bool use_256(const Problem& p, int variant, bool split_ok) {
+// worth: what the 256^2 pipeline is worth per PADDED flop against the 128^2 kernel — 1.25 for the dense GEMM and the 8-wave kernel (measured
+// 1.15-1.3 PF vs 0.85-1.0 PF); the convolution's one-wave-per-SIMD pipeline asks with 2.0 (r5: conv_w4 1.3 PF against 0.61 PF of the
+// gathering 128^2 kernel on the same 384-channel launches, profiles/r5_vae21_decode_rocprofv3_kernel_stats.csv)
+inline bool use_256(const Problem& p, int variant, bool split_ok, double worth = 1.25) {
     if (variant == 1 || !split_ok) return false;
     if (variant == 2) return true;
     const int64_t t256 = (int64_t)((p.M + 255) / 256) * ((p.N + 255) / 256);
     if (t256 < 192) return false;                      // does not fill the 256 CUs
-    // padded work of both tilings; the 256^2 pipeline is worth ~1.25x per flop (measured 1.15-1.3 PF vs 0.85-1.0 PF)
+    // padded work of both tilings
     const int64_t t128 = (int64_t)((p.M + 127) / 128) * ((p.N + 127) / 128);
-    return (double)t256 * 4.0 / 1.25 <= (double)t128;
+    return (double)t256 * 4.0 / worth <= (double)t128;
 }
 
 template <int EPI, class ALoad>
