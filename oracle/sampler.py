@@ -110,3 +110,31 @@ def tts(transformer, latent, model_input, noise, sigmas, lfz, randn, sde=True, g
             temp_x0 = latent[:, -lfz:] + (nxt - sigmas[i]) * current_pred[:, -lfz:]
         latent = torch.cat([hist(min(S - 1, i + 1)), temp_x0], dim=1)
     return latent
+
+
+def long_video_5b(transformer, vae_decode, first_history, n_chunks, sigmas, lfz, randn):
+    """The FramePack chunk loop around euler_5b, fastvideo/sample/sample_5b.py:920-1097, as that script runs it for image/video-to-video
+    input (`not t2v`), restated by reading (the hand-over lines sit between dataset, tokenizer and mp4 side effects and cannot be cut out
+    and executed the way the inner loop is):
+
+      chunk k (`step_sample`):  the conditioning latents `model_input` so far are padded with `lfz` frames (:1093-1095 `model_input_1`;
+                                for the first chunk wan_i2v.generate hands back the same thing), fresh noise of that padded shape is drawn
+                                (:945 `torch.randn_like(model_input_1)`) and only its last lfz frames are used (:953): latent = [history | noise];
+                                Euler steps with the CLEAN history put back in front after every step (:1031-1034) = euler_5b;
+                                the lfz new frames are appended to the conditioning latents (:1043-1049) and decoded on their own
+                                (:1051-1052 `scale(vae, model_input[:, -lfz:])` -> vae.decode of those frames in fp32, :479-489).
+
+    transformer(latent, i, "cond", k): velocity for chunk k's caption; vae_decode(z) -> video or None; randn(shape) replays the noise.
+    Returns (all latents [C, F0 + n_chunks * lfz, H, W], [decoded chunk, ...])."""
+    model_input = first_history
+    videos = []
+    for k in range(n_chunks):
+        C, _, H, W = model_input.shape
+        model_input_1 = torch.cat([model_input, torch.zeros(C, lfz, H, W, dtype=model_input.dtype, device=model_input.device)], dim=1)
+        noise = randn(model_input_1.shape)
+        latent = torch.cat([model_input_1[:, :-lfz], noise[:, -lfz:]], dim=1)
+        latent = euler_5b(lambda lat, i, which: transformer(lat, i, which, k), latent, model_input_1, sigmas, lfz)
+        model_input = torch.cat([model_input, latent[:, -lfz:]], dim=1)
+        if vae_decode is not None:
+            videos.append(vae_decode(model_input[:, -lfz:].float()))
+    return model_input, videos

@@ -39,6 +39,11 @@ CASES = {
     # BASELINE.json configs[2] literally (bench.py::bench_14b): 65-frame 544x960 clip, latent [16,17,68,120] + y, L = 27 810. Its oracle leg is
     # 2.6 PFLOP per CFG step: only the device gold (oracle/devgold.py, the same functions on the GPU in fp32) can afford it.
     "14b_full": dict(family="wan", F=17, H=68, W=120, lfz=9, steps=50, shift=3.0, i=10, n_text=77, guide=5.0, rand_num_img=0.6),
+    # row N3 (tests/test_zx_sampling_loops_gpu.py): the 5b geometry under the product's sampling loops — a 6-step SDE / time-travel chunk
+    # (two look-aheads + the stale reuse of sample_tts.py:820-868), a 10-step ODE chunk, and the 2-step chunks of the long-video loop
+    "5b_tts6": dict(family="wan23", F=13, H=44, W=80, lfz=8, steps=6, shift=7.0, i=0, n_text=77),
+    "5b_ode10": dict(family="wan23", F=13, H=44, W=80, lfz=8, steps=10, shift=7.0, i=0, n_text=77),
+    "5b_lv2": dict(family="wan23", F=13, H=44, W=80, lfz=8, steps=2, shift=7.0, i=0, n_text=77),
     # plumbing checks of this file on the build container (tests/test_step_job_cpu.py): 2-layer models of width 512
     "tiny5b": dict(family="wan23", F=13, H=12, W=16, lfz=8, steps=50, shift=7.0, i=10, n_text=20, tiny=True),
     "tiny14b": dict(family="wan", F=13, H=12, W=16, lfz=9, steps=50, shift=3.0, i=10, n_text=20, guide=5.0, rand_num_img=0.6, tiny=True),
@@ -73,11 +78,13 @@ def sigmas(name):
     return [float(s) for s in sampler.get_sampling_sigmas(c["steps"], c["shift"])]
 
 
-def seq_len(name):
+def seq_len(name, F=None):
+    """the FramePack plan of the case; F overrides the case's frame count (the long-video loop's history grows chunk by chunk)."""
     from yume_amd import framepack
     c = CASES[name]
-    n_sel = c["F"] - 9 if c["family"] == "wan" else None      # wan/modules/model.py:781: the 14B file selects its branch with a literal 9
-    return framepack.pack_plan(c["F"], c["H"], c["W"], c["lfz"], n_sel)
+    F = c["F"] if F is None else F
+    n_sel = F - 9 if c["family"] == "wan" else None           # wan/modules/model.py:781: the 14B file selects its branch with a literal 9
+    return framepack.pack_plan(F, c["H"], c["W"], c["lfz"], n_sel)
 
 
 def euler(name, latent, pred, i):
@@ -90,10 +97,14 @@ def euler(name, latent, pred, i):
 class _TimedSD:
     """HashedDitStateDict with the generation time kept apart from the forward's own time."""
 
-    def __init__(self, sd, sync=False):
-        self.sd, self.gen_s, self.sync = sd, 0.0, sync
+    def __init__(self, sd, sync=False, cache=None):
+        self.sd, self.gen_s, self.sync, self.cache = sd, 0.0, sync, cache
 
     def __getitem__(self, k):
+        if self.cache is not None:                 # a loop of forwards on one device keeps the generated fp32 tensors (5B: 20 GB of 288)
+            if k not in self.cache:
+                self.cache[k] = self.sd[k]
+            return self.cache[k]
         if self.sync:
             torch.cuda.synchronize()
         t0 = time.time()
@@ -111,8 +122,10 @@ class _TimedSD:
 
 
 @torch.no_grad()
-def oracle_forward(name, which, latent=None, i=None, threads=None, device=None):
+def oracle_forward(name, which, latent=None, i=None, threads=None, device=None, ctx=None, weight_cache=None):
     """one reference-restatement forward of the case -> (pred fp32 [Cout, lfz, H, W] on the host, forward seconds, weight-generation seconds).
+    latent: another latent of the case's height / width (its frame count sets the FramePack plan); ctx: other text embeddings [n, 4096];
+    weight_cache: a dict that keeps the generated weights between the calls of a sampling loop (same values: the rule is a pure function).
     device None: on the host cores (the specification). device "cuda": the same oracle/dit.py functions on the GPU in fp32 — the device gold
     of oracle/devgold.py (weights from the same hashed rule evaluated on the GPU, bit for bit), for the sizes the host cannot afford."""
     import contextlib
@@ -129,10 +142,11 @@ def oracle_forward(name, which, latent=None, i=None, threads=None, device=None):
     cuda = dev.type == "cuda"
     inp = {k: v.to(dev) for k, v in make_inputs(name).items()}
     latent = inp["latent"] if latent is None else latent.to(dev)
+    text = inp[which] if ctx is None else ctx.to(dev)
     i = c["i"] if i is None else i
-    plan = seq_len(name)
+    plan = seq_len(name, latent.shape[1])
     sg = sigmas(name)
-    sd = _TimedSD(synth.HashedDitStateDict(cfg, c["family"], SEED, device=dev), sync=cuda)
+    sd = _TimedSD(synth.HashedDitStateDict(cfg, c["family"], SEED, device=dev), sync=cuda, cache=weight_cache)
     orig = odit.attention
     if not on_gpu:
         odit.attention = fullsize.attention_fp32
@@ -144,10 +158,10 @@ def oracle_forward(name, which, latent=None, i=None, threads=None, device=None):
             if c["family"] == "wan23":
                 t = torch.cat([torch.zeros(plan.n_hist_tok, dtype=torch.float64),
                                torch.full((plan.n_new_tok,), sg[i] * 1000.0, dtype=torch.float64)]).unsqueeze(0).to(dev)
-                pred = odit.forward_wan23(sd, cfg, latent, t, inp[which], plan.seq_len, c["lfz"], True)
+                pred = odit.forward_wan23(sd, cfg, latent, t, text, plan.seq_len, c["lfz"], True)
             else:
                 t = torch.tensor([sg[i] * 1000.0], device=dev)
-                pred = odit.forward_wan(sd, cfg, latent, t, inp[which], plan.seq_len, inp["clip_fea"][0], inp["y"],
+                pred = odit.forward_wan(sd, cfg, latent, t, text, plan.seq_len, inp["clip_fea"][0], inp["y"],
                                         rand_num_img=c["rand_num_img"], latent_frame_zero=c["lfz"])
             pred = pred.cpu()                                   # (synchronises)
             dt = time.time() - t0

@@ -205,6 +205,32 @@ def test_context_cache_is_bit_identical(name):
 
 
 @pytest.mark.parametrize("name", ["dit_wan23_packed_f13", "dit_wan_packed_f13"])
+def test_trimmed_last_block_returns_the_same_velocity(name):
+    """the history tokens are dropped in front of unpatchify (wan23/modules/model.py:860, wan/modules/model.py:1003-1005), so
+    the LAST block needs their K / V only; engine.trim_last_block skips their queries, o projection, cross-attention and FFN there. The rows
+    that are computed go through the same kernels on row-offset views: the returned velocity has to be the same (bits at this size)."""
+    fx = load_golden(name)
+    fam = fx["family"]
+    sd = synth.make_dit_state_dict(fx["cfg"], fam, fx["seed"])
+    m = build_model(fam, fx["cfg"], sd)
+    inp = {k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in fx["inputs"].items()}
+
+    def run():
+        if fam == "wan23":
+            return m([inp["x"]], t=fx["t"].to(DEV), context=[inp["context"]], seq_len=fx["seq_len"], latent_frame_zero=fx["lfz"], flag=True)[0].clone()
+        return m([inp["x"]], t=fx["t"].to(DEV), context=[inp["context"]], seq_len=fx["seq_len"], clip_fea=inp["clip_fea"], y=[inp["y"]],
+                 rand_num_img=0.6, latent_frame_zero=fx["lfz"])[0].clone()
+    assert m.engine.trim_last_block is False
+    base = run()
+    m.engine.trim_last_block = True
+    got = run()
+    m.engine.trim_last_block = False
+    assert got.shape == base.shape and torch.isfinite(got).all()
+    assert torch.equal(got, base), (got - base).abs().max()
+    assert torch.equal(run(), base)
+
+
+@pytest.mark.parametrize("name", ["dit_wan23_packed_f13", "dit_wan_packed_f13"])
 def test_q_prescale_switch_computes_the_same_model(name):
     """The engine folds softmax scale * log2(e) into the q RMSNorm weight and tells the attention kernel so (YUME_ATTN_Q_PRESCALED);
     engine.q_prescale = False keeps the scale inside the kernel. Same model, one bf16 rounding of q placed differently: both meet the

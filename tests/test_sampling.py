@@ -168,3 +168,49 @@ def test_oracle_and_host_loops_match_the_reference_script_fixture(dtype):
         for i in range(n):
             assert torch.equal(t[i, 0, :n0], torch.zeros(n0, dtype=torch.float64))
             assert torch.equal(t[i, 0, n0:], torch.ones(t.shape[2] - n0, dtype=torch.float64) * (sig[i] * 1000.0))
+
+
+# ---- the FramePack chunk loop (sample_5b.py:920-1097): product vs the oracle's restatement, stand-in model and VAE on the CPU ----
+class _FakeModel:
+    """WanModel.forward's call shape for make_velocity_5b (list in, list out, per-token t), a deterministic field inside."""
+
+    def __init__(self, lfz):
+        self.lfz, self.p, self.calls = lfz, torch.nn.Parameter(torch.zeros(1)), []
+
+    def parameters(self):
+        return iter([self.p])
+
+    def field(self, lat, sigma, ctx):
+        return torch.tanh(lat[:, -self.lfz:] * 0.7 + lat[:, :1].mean() + ctx.mean()) * (0.5 + sigma)
+
+    def __call__(self, xs, t, context, seq_len, latent_frame_zero, flag):
+        assert flag and latent_frame_zero == self.lfz and t.shape == (1, seq_len) and t[0, 0] == 0
+        self.calls.append((xs[0].shape[1], seq_len))
+        return [self.field(xs[0], float(t[0, -1]) / 1000.0, context[0])]
+
+
+def test_long_video_loop_matches_the_oracle_restatement():
+    from yume_amd import framepack
+    g = torch.Generator().manual_seed(11)
+    lfz, steps, shift, F0, H, W = 3, 4, 7.0, 5, 4, 6
+    h0 = torch.randn(6, F0, H, W, generator=g)
+    ctxs = [torch.randn(7, 8, generator=g) for _ in range(3)]
+    sig = sampling.sampling_sigmas(steps, shift)
+    fm = _FakeModel(lfz)
+
+    class _Vae:
+        def decode(self, zs):
+            return [zs[0] * 2.0 + 1.0]
+    hist, vids = sampling.long_video_5b(fm, _Vae(), h0, ctxs, steps, shift, lfz, generator=torch.Generator().manual_seed(12))
+    g2 = torch.Generator().manual_seed(12)
+
+    def randn(shape):               # the script draws the padded shape and reads its last lfz frames; the product draws those frames only
+        out = torch.zeros(tuple(shape))
+        out[:, -lfz:] = torch.randn((shape[0], lfz, shape[2], shape[3]), generator=g2)
+        return out
+    want, wv = osamp.long_video_5b(lambda lat, i, which, k: fm.field(lat, sig[i], ctxs[k]), lambda z: z * 2.0 + 1.0, h0, 3, sig, lfz, randn)
+    assert hist.shape == (6, F0 + 3 * lfz, H, W)
+    assert torch.allclose(hist, want, atol=1e-6) and all(torch.allclose(a, b, atol=1e-6) for a, b in zip(vids, wv))
+    assert torch.equal(hist[:, :F0], h0)
+    assert [c[0] for c in fm.calls] == [F0 + lfz] * steps + [F0 + 2 * lfz] * steps + [F0 + 3 * lfz] * steps
+    assert [c[1] for c in fm.calls[::steps]] == [framepack.pack_plan(F0 + (k + 1) * lfz, H, W, lfz).seq_len for k in range(3)]

@@ -45,6 +45,11 @@ class DiTEngine:
         # conditioning, not on the latent or the timestep; with cache_context they are computed once per conditioning
         # tensor (same object, same version) instead of once per denoise step. Off by default = the reference's work.
         self.cache_context = False
+        # both families drop the history tokens before unpatchify (wan23/modules/model.py:860, wan/modules/model.py:1003-1005),
+        # so in the LAST block the history rows only have to supply K / V to the self-attention: with trim_last_block their queries, o
+        # projection, cross-attention and FFN are not computed (5B: 2420 of 9460 rows of one block). The returned velocity is unchanged
+        # (GEMM / attention rows are independent). Off by default = the reference's work; bench.py reports it beside the headline.
+        self.trim_last_block = os.environ.get("YUME_TRIM_LAST_BLOCK", "0") == "1"
         # kernel selection passed to every GEMM / attention call: 0 = automatic (product setting); tests set (1, 1) to run the
         # whole model on the independent 128x128-tile GEMM and register-staged attention kernels as a cross-check
         self.gemm_variant = 0
@@ -268,8 +273,10 @@ class DiTEngine:
             ops.rmsnorm_rows_periodic(kc.view(nk * nb, C), C, nk_w, self.model.eps)
         return kc, vct
 
-    def _blocks(self, xs, L, tab, row_idx, R, rope, n_rope, ctx, n_img, ctx_fresh=True, n_keys=None, only=None, cache=None):
+    def _blocks(self, xs, L, tab, row_idx, R, rope, n_rope, ctx, n_img, ctx_fresh=True, n_keys=None, only=None, cache=None, n_trim=0):
         """xs fp32 [L, C] in/out. tab fp32 [nb, R, 6, C]; rope fp32 [n_rope, 64, 2] (n_rope == L here).
+        n_trim: the first n_trim rows of the LAST block's output are not needed by the caller (history tokens in front of the head): that
+        block computes K / V for every row but everything behind the QKV projection for the rows [n_trim, L) only; xs[:n_trim] is then stale.
         With sequence parallelism L is this rank's (padded) chunk and n_keys the true global token count.
         only: run just these block indices (tab[j] then belongs to only[j]) — the WanAttentionBlock.forward seam.
         cache: (mode, cache_list, tensors) block-residual cache of wan/modules/model.py:985-1000: mode 'record' appends
@@ -301,6 +308,11 @@ class DiTEngine:
             tb = tab[j if only is not None else i]                      # [R, 6, C]
             shift_sa, scale_sa, gate_sa = tb[:, 0], tb[:, 1], tb[:, 2]
             shift_ff, scale_ff, gate_ff = tb[:, 3], tb[:, 4], tb[:, 5]
+            s = n_trim if j == len(ids) - 1 else 0                      # rows [s, L) are the ones whose output is wanted
+            if s:
+                self._trimmed_block(xs, L, s, d, i, tb, ts, row_idx, rope, eps, h, qk, vt, att, ff, kc_t, vct_t, ntxt,
+                                    (kc_i, vct_i, n_img) if n_img else None)
+                continue
             # --- self attention
             T("adaln", ops.adaln_modulate, xs, scale_sa, shift_sa, ts, row_idx, True, h, 0, eps)
             T("gemm_qkv", ops.gemm_bf16, h, d["wqkv"], d["bqkv"], qk, EPI_BF16_SPLITT, out_t=vt, n_split=2 * C, variant=self.gemm_variant)
@@ -340,6 +352,39 @@ class DiTEngine:
             T("gemm_ffn2", ops.gemm_bf16, ff, d["w2"], d["b2"], xs, EPI_RESID, gate=gate_ff, gate_stride=ts, row_idx=row_idx, variant=self.gemm_variant)
             if cache is not None and cache[0] == "record" and i in cache[1]:
                 cache[2].append((xs - x_in).to(torch.bfloat16).unsqueeze(0))     # reference keeps [B, L, C] bf16
+
+    def _trimmed_block(self, xs, L, s, d, i, tb, ts, row_idx, rope, eps, h, qk, vt, att, ff, kc_t, vct_t, ntxt, img):
+        """the block of _blocks with everything behind the QKV projection restricted to the rows [s, L) (trim_last_block): the same
+        kernel calls on row-offset views, so the rows that are computed go through the same arithmetic."""
+        m = self.model
+        C, H = m.dim, m.num_heads
+        T = self._timed
+        shift_sa, scale_sa, gate_sa = tb[:, 0], tb[:, 1], tb[:, 2]
+        shift_ff, scale_ff, gate_ff = tb[:, 3], tb[:, 4], tb[:, 5]
+        xo, ho, ao, fo, qo = xs[s:], h[s:], att[s:], ff[s:], qk[s:, :C]
+        ro = row_idx[s:] if row_idx is not None else None
+        n = L - s
+        T("adaln", ops.adaln_modulate, xs, scale_sa, shift_sa, ts, row_idx, True, h, 0, eps)
+        T("gemm_qkv", ops.gemm_bf16, h, d["wqkv"], d["bqkv"], qk, EPI_BF16_SPLITT, out_t=vt, n_split=2 * C, variant=self.gemm_variant)
+        T("rmsnorm_rope", ops.rmsnorm_rope, qk, C, 2, d["nqk"], eps, rope)
+        T("attn_self", ops.attn_fwd, qo, qk[:, C:], vt, ao, n, L, H, variant=self.attn_variant, q_prescaled=self.q_prescale, kv_padded=True)
+        T("gemm_o", ops.gemm_bf16, ao, d["wo"], d["bo"], xo, EPI_RESID, gate=gate_sa, gate_stride=ts, row_idx=ro, variant=self.gemm_variant)
+        if "n3w" in d:
+            T("adaln", ops.adaln_modulate, xo, d["n3w"], d["n3b"], 0, None, False, ho, 0, eps)
+        else:
+            ops.cast_bf16(xo, n, ho)
+        T("gemm_cross_q", ops.gemm_bf16, ho, d["wq_c"], d["bq_c"], qo, EPI_BF16, variant=self.gemm_variant)
+        T("rmsnorm_rope", ops.rmsnorm_rope, qo, C, 1, d["nq_c"], eps)
+        T("attn_cross", ops.attn_fwd, qo, kc_t[:, i * C:(i + 1) * C], vct_t[i * C:(i + 1) * C], ao, n, ntxt, H, variant=self.attn_variant,
+          q_prescaled=self.q_prescale, kv_padded=True)
+        if img is not None:
+            kc_i, vct_i, n_img = img
+            T("attn_cross", ops.attn_fwd, qo, kc_i[:, i * C:(i + 1) * C], vct_i[i * C:(i + 1) * C], ao, n, n_img, H, accumulate=True,
+              variant=self.attn_variant, q_prescaled=self.q_prescale, kv_padded=True)
+        T("gemm_cross_o", ops.gemm_bf16, ao, d["wo_c"], d["bo_c"], xo, EPI_RESID, variant=self.gemm_variant)
+        T("adaln", ops.adaln_modulate, xo, scale_ff, shift_ff, ts, ro, True, ho, 0, eps)
+        T("gemm_ffn0", ops.gemm_bf16, ho, d["w1"], d["b1"], fo, EPI_BF16_GELU, variant=self.gemm_variant)
+        T("gemm_ffn2", ops.gemm_bf16, fo, d["w2"], d["b2"], xo, EPI_RESID, gate=gate_ff, gate_stride=ts, row_idx=ro, variant=self.gemm_variant)
 
     # ------------------------------------------------------------------ one block through the engine (operator seam)
     @torch.no_grad()
@@ -493,7 +538,8 @@ class DiTEngine:
             if cache is not None:
                 raise NotImplementedError("cache_sample is not combined with sequence parallelism")
             return self._forward_sp(xs, L, n_hist, tab.view(nb, R, 6, C), row_idx, R, rope, ctx, n_img, ctx_fresh, e, grid)
-        self._blocks(xs, L, tab.view(nb, R, 6, C), row_idx, R, rope, L, ctx, n_img, ctx_fresh, cache=cache)
+        n_trim = n_hist if (self.trim_last_block and cache is None) else 0
+        self._blocks(xs, L, tab.view(nb, R, 6, C), row_idx, R, rope, L, ctx, n_img, ctx_fresh, cache=cache, n_trim=n_trim)
         ridx_new = row_idx[n_hist:] if row_idx is not None else None
         return self._head(xs[n_hist:], ridx_new, e, R, grid)
 

@@ -51,7 +51,9 @@ def ensure_counters(device):
     idx = device.index if device.index is not None else torch.cuda.current_device()
     t = _counters.get(idx)
     if t is None:
-        if torch.cuda.is_current_stream_capturing():
+        with torch.cuda.device(idx):                       # (the capture state of THAT device's current stream)
+            capturing = torch.cuda.is_current_stream_capturing()
+        if capturing:
             raise RuntimeError("yume_amd: the ticket-counter workspace must be registered before a stream capture begins "
                                "(call yume_amd.ops.ensure_counters(device) once outside the capture)")
         lib = _lib.load()
