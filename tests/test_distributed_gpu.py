@@ -116,20 +116,29 @@ def _run_bench(extra_args, env_extra, timeout=900):
     return r, (json.loads(lines[-1]) if lines else None)
 
 
-def test_bench_gpus_2_launches_two_ranks_itself():
-    """`python bench.py --gpus 2` without torchrun's env must BECOME the 2-rank job (the reference launches one process per GPU:
-    fastvideo/sample/sample_5b.py:1124-1134, index = (step-1)*world + rank at :782-785). The single-GPU test box has one device, so the two
-    ranks share cuda:0 and talk gloo (YUME_BENCH_SHARE_GPU=1, test mode); everything else is bench's own N > 1 control flow: per-rank
-    chains, weight replication from rank 0, barrier-bracketed timing, max over ranks, one JSON line from rank 0."""
-    r, line = _run_bench(["--gpus", "2", "--layers", "1", "--steps", "2", "--warmup", "1", "--no-vae"],
-                         {"YUME_BENCH_SHARE_GPU": "1"})
+def test_bench_gpus_8_launches_eight_ranks_itself(tmp_path):
+    """`python bench.py --gpus 8` without torchrun's env must BECOME the 8-rank job the driver's SCALE run launches (the reference starts one
+    process per GPU: fastvideo/sample/sample_5b.py:1124-1134, index = (step-1)*world + rank at :782-785). The test box has one device, so the
+    eight ranks share cuda:0 and talk gloo (YUME_BENCH_SHARE_GPU=1, test mode); everything else is bench's own N = 8 control flow: rank 0
+    builds the library while seven wait at the barrier, eight model builds, weight replication from rank 0, per-rank chains,
+    barrier-bracketed timing, max over ranks, one JSON line from rank 0 — and the host-side rules of DESIGN §6: every rank caps its thread
+    team at cpu_count // 8 (<= 16), and rank 0's CPU legs (cpu_baseline, parity) start only after every rank's GPU work is over."""
+    import json
+    r, line = _run_bench(["--gpus", "8", "--layers", "1", "--steps", "2", "--warmup", "1", "--no-vae"],
+                         {"YUME_BENCH_SHARE_GPU": "1", "YUME_BENCH_RANK_LOG": str(tmp_path)}, timeout=1200)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert line is not None, r.stdout[-2000:]
-    assert line["n_gpus"] == 2 and line["scaling"] == "weak"
-    assert len(line["chain_checksums"]) == 2 and line["chain_checksums"][0] != line["chain_checksums"][1]
+    assert line["n_gpus"] == 8 and line["scaling"] == "weak"
+    assert len(line["chain_checksums"]) == 8 and len(set(line["chain_checksums"])) == 8          # eight different chains
     assert line["weight_broadcast_collectives"] > 0
-    assert line["config"]["parallelism"].startswith("dp2")
-    assert line["value"] > 0 and abs(line["value"] - 2 * 2 / (line["ms_per_step"] * 2e-3)) < 1e-6 * line["value"]
+    assert line["config"]["parallelism"].startswith("dp8")
+    assert line["value"] > 0 and abs(line["value"] - 8 * 2 / (line["ms_per_step"] * 2e-3)) < 1e-6 * line["value"]
+    cap = max(1, min(16, (os.cpu_count() or 8) // 8))
+    assert line["host_threads_per_rank"] == [cap] * 8
+    recs = [json.load(open(tmp_path / f"rank{k}.json")) for k in range(8)]
+    assert sorted(x["rank"] for x in recs) == list(range(8)) and len({x["pid"] for x in recs}) == 8
+    assert all(x["threads"] == cap for x in recs)
+    assert line["cpu_legs_started_at"] >= max(x["gpu_work_done_at"] for x in recs)
     # an N > 1 line is complete: rank 0 emits the CPU baseline and the parity figure at any world size
     assert line["cpu_baseline"]["value"] > 0 and line["cpu_baseline"]["kind"] == "port" and line["cpu_baseline"]["host_threads"] >= line["cpu_baseline"]["cores"]
     assert line["parity"]["block"]["rel_l2"] <= 1e-2

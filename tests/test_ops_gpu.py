@@ -532,11 +532,13 @@ def test_gemm_small_m_split_k_matches_plain(M, N, K):
 
 def test_calibration_microkernel_reports_a_plausible_sustained_rate():
     """yume_calibrate_mfma through yume_amd.calibrate (bench.py's `calibration`): the pure-MFMA rate on random operands must lie between a
-    tenth of and a little above the nominal 2.5 PFLOP/s, the implied clock and the kernel's own s_memtime reading must agree, and the fixed
-    8192^3 reference launch must land where the product GEMM does."""
+    tenth of and a little above the nominal 2.5 PFLOP/s and the fixed 8192^3 reference launch must land where the product GEMM does. The
+    kernel's own s_memtime reading is printed next to the implied clock (informational: whether s_memtime ticks at the shader clock is a
+    firmware property, not the product's — ADVICE r5)."""
     from yume_amd import calibrate
     m = calibrate.mfma_sustained(DEV, settle_s=0.05, measure_s=0.1)
     assert 250.0 < m["tflops"] < 2700.0 and 0.25 < m["clock_ghz"] < 2.6
-    assert m["s_memtime_ghz"] is None or abs(m["s_memtime_ghz"] - m["clock_ghz"]) < 0.25 * m["clock_ghz"]
+    print(f"calibration: {m['tflops']:.0f} TF/s, implied clock {m['clock_ghz']:.3f} GHz, s_memtime {m['s_memtime_ghz']} GHz, measured {m['measured_s']:.3f} s")
+    assert m["measured_s"] >= 0.08
     g = calibrate.gemm_reference(DEV, reps=5)
     assert 300.0 < g["tflops"] < 2500.0

@@ -340,7 +340,7 @@ __global__ __launch_bounds__(256) void calibrate_mfma_kernel(long long iters, un
         u32x4 wx, wy;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            // two bf16 per word: sign and 7 mantissa bits random, exponent 125..128 (|v| in [0.25, 4)) — finite sums whatever the count
+            // two bf16 per word: sign and 7 mantissa bits random, exponent field 125 or 127 (|v| in [0.25, 0.5) or [1, 2)) — finite sums whatever the count
             h = h * 1664525u + 1013904223u;
             wx[i] = (h & 0x80ff80ffu) | 0x3e803e80u | ((h >> 3) & 0x01800180u);
             h = h * 1664525u + 1013904223u;
