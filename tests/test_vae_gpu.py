@@ -390,3 +390,36 @@ def test_conv_halo_head_vs_torch(with_cache):
         for sl in ((slice(None, Cout), 0), (slice(None, Cout), slice(None), 0), (slice(None, Cout), slice(None), -1),
                    (slice(None, Cout), slice(None), slice(None), 0), (slice(None, Cout), slice(None), slice(None), -1)):
             assert rel_l2(got[sl], want[(slice(None),) + sl[1:]]) < 5e-3
+
+
+@pytest.mark.parametrize("C,T,H,W,with_cache", [(96, 3, 136, 128, True), (96, 2, 130, 150, False), (160, 2, 132, 130, True), (160, 1, 128, 128, False)])
+def test_conv_halo_n_96_and_160_channel_levels_vs_torch(C, T, H, W, with_cache):
+    """conv_halo_n_kernel (r6): the 3x3x3 convolutions of the 96-channel level of the Wan2.1 VAE (wan/modules/vae.py:369-472) and of the
+    160-channel level of the Wan2.2 encoder (wan23/modules/vae2_2.py:506-622) — halo tile + weight ring in LDS. Whole and ragged tiles
+    (right / bottom edge), with the causal cache and without it, the plain and the fused-shortcut epilogue; every border face checked."""
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    x = rnd(C, T, H, W, seed=41).bfloat16().float()
+    cache = rnd(C, 2, H, W, seed=42).bfloat16().float() if with_cache else None
+    w = (rnd(C, C, 3, 3, 3, seed=43) * (27 * C) ** -0.5).bfloat16().float()
+    b = rnd(C, seed=44) * 0.1
+    xin = torch.cat([cache, x], dim=1) if with_cache else F.pad(x, (0, 0, 0, 0, 2, 0))
+    want = F.conv3d(F.pad(xin.unsqueeze(0), (1, 1, 1, 1)), w, b)[0]
+    out = torch.full((T, H, W, C), 7.0, dtype=torch.bfloat16, device=DEV)
+    V.conv3d_cl(cl(x), cl(cache) if with_cache else None, pack_w(w), b.to(DEV), C, (3, 3, 3), (1, 1, 1), (2, 1, 1), False, out,
+                V.EPI_BF16, zero_page=zero_page())
+    got = ncthw(out)
+    assert torch.isfinite(got).all()
+    assert rel_l2(got, want) < 5e-3, rel_l2(got, want)
+    assert (got - want).abs().max() <= 2.0 ** -6 * want.abs().max() + 1e-3
+    for sl in ((slice(None), 0), (slice(None), -1), (slice(None), slice(None), 0), (slice(None), slice(None), -1),
+               (slice(None), slice(None), slice(None), 0), (slice(None), slice(None), slice(None), -1)):
+        assert rel_l2(got[sl], want[sl]) < 5e-3, sl
+    skip = rnd(C, T, H, W, seed=45).bfloat16().float()
+    V.conv3d_cl(cl(x), cl(cache) if with_cache else None, pack_w(w), b.to(DEV), C, (3, 3, 3), (1, 1, 1), (2, 1, 1), False, out,
+                V.EPI_ADD, add=cl(skip), zero_page=zero_page())
+    assert rel_l2(ncthw(out), want + skip) < 5e-3
+    # the same launch twice: equal bits (no stale LDS, no ordering race between the DMA ring and the fragment reads)
+    out2 = torch.empty_like(out)
+    V.conv3d_cl(cl(x), cl(cache) if with_cache else None, pack_w(w), b.to(DEV), C, (3, 3, 3), (1, 1, 1), (2, 1, 1), False, out2,
+                V.EPI_ADD, add=cl(skip), zero_page=zero_page())
+    assert torch.equal(out, out2)

@@ -14,6 +14,7 @@
 #include "gemm_core.hpp"
 #include "conv_w4.hpp"
 #include "conv_halo.hpp"
+#include "conv_halo_n.hpp"
 
 using namespace gemm_core;
 
@@ -251,6 +252,23 @@ extern "C" int yume_conv3d_cl(const void* x, const void* cache, int64_t ldc, int
         const int64_t nt = To * hp.tiles_h * hp.tiles_w;
         YUME_REQUIRE(nt < (1ll << 31), "conv3d_cl: too many tiles");
         hipLaunchKernelGGL(conv_halo::conv_halo16_kernel<0>, dim3((unsigned)nt), dim3(256), 0, s, hp);
+        YUME_CHECK_LAUNCH("conv3d_cl");
+        return YUME_OK;
+    }
+    if (conv_halo_n::applies(Cin, Cout, kt, kh, kw, st, sh, sw, pt, ph, pw, ups, Hin, Win, Ho, Wo, ldc, ldo, ldw, epi, ldadd)) {
+        // 96 / 160-channel levels (Cin in whole 32-channel slices, one N tile of Cout): halo tile + weight ring in LDS (conv_halo_n.hpp)
+        YUME_REQUIRE(epi != YUME_CONV_EPI_ADD || add != nullptr, "conv3d_cl: ADD epilogue needs an addend");
+        conv_halo_n::Params hp;
+        hp.x = al.x; hp.cache = al.cache; hp.w = (const unsigned short*)W; hp.bias = bias; hp.out = (unsigned short*)out;
+        hp.add = (const unsigned short*)add;
+        hp.ldc = ldc; hp.ldw = ldw; hp.ldo = ldo; hp.ldadd = ldadd;
+        hp.Tin = (int)Tin; hp.H = (int)Hin; hp.W = (int)Win; hp.C = (int)Cin; hp.To = (int)To; hp.cout = (int)Cout; hp.kt = kt; hp.pt = pt;
+        static const bool log_on = [] { const char* v = getenv("YUME_CONV_LOG"); return v && atoi(v) != 0; }();
+        if (log_on) fprintf(stderr, "[conv3d_cl] halo_n M=%lld Cin=%lld Cout=%lld k=%dx%dx%d\n", (long long)M, (long long)Cin, (long long)Cout, kt, kh, kw);
+        const bool addep = epi == YUME_CONV_EPI_ADD;
+        const int rc = conv_halo_n::instance(Cin, Cout) == 96 ? conv_halo_n::launch_inst<6, 8, 8, 64>(hp, To, Ho, Wo, addep, s)
+                                                               : conv_halo_n::launch_inst<10, 4, 4, 64>(hp, To, Ho, Wo, addep, s);
+        YUME_REQUIRE(rc == 0, "conv3d_cl: too many tiles");
         YUME_CHECK_LAUNCH("conv3d_cl");
         return YUME_OK;
     }
