@@ -58,22 +58,27 @@ __device__ __forceinline__ i32x4 frame_srd(const Params& p, int ti) {
 #define HN_DMA(voff, sbase, lds) \
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds) : "memory")
 
+#ifndef HN_ABLATE
+#define HN_ABLATE 0       // experiments only (timing, wrong results): 1 = no DMA inside the loop, 2 = no waits / barriers, 4 = fragments read at tap 0 of a step only
+#endif
 template <int N>
-__device__ __forceinline__ void wait_bar() {       // everything but the last N vector-memory operations of this wave has landed; all LDS reads are back
+__device__ __forceinline__ void wait_bar() {
+    if constexpr (HN_ABLATE & 2) return;       // everything but the last N vector-memory operations of this wave has landed; all LDS reads are back
     asm volatile("s_waitcnt vmcnt(%c0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory");
 }
 
-template <int NJ, int MI, int TH, int TW>
+template <int NJ, int MI, int TH, int TW, int NW>
 struct Geo {
-    static_assert(TW % 16 == 0 && (TH * TW) / 16 == 4 * MI, "4 waves x MI m-tiles of 16 columns cover the TH x TW region");
+    static_assert(NW == 4 || NW == 8, "one or two waves per SIMD");
+    static_assert(TW % 16 == 0 && (TH * TW) / 16 == NW * MI, "NW waves x MI m-tiles of 16 columns cover the TH x TW region");
     static constexpr int MTR = TW / 16;                    // m-tiles per row
     static constexpr int HR = TH + 2, HC = TW + 2, NPOS = HR * HC;
     static constexpr int NPIECE = (NPOS + 15) / 16;        // pieces of 16 positions x 64 B
-    static constexpr int PPW = (NPIECE + 3) / 4;           // halo pieces per wave and step
-    static constexpr int HALO_BYTES = PPW * 4 * 1024;
+    static constexpr int PPW = (NPIECE + NW - 1) / NW;     // halo pieces per wave and step
+    static constexpr int HALO_BYTES = PPW * NW * 1024;
     static constexpr int HPT = (PPW + 7) / 8;              // halo pieces issued per tap (taps 0..7 of the step before)
-    static constexpr int NSW = (NJ + 3) / 4;               // weight pieces (16 rows x 64 B = one n-tile) per wave and tap
-    static constexpr int WSLAB = NSW * 4 * 1024;
+    static constexpr int NSW = (NJ + NW - 1) / NW;         // weight pieces (16 rows x 64 B = one n-tile) per wave and tap
+    static constexpr int WSLAB = NSW * NW * 1024;
     static constexpr int LDS = 2 * HALO_BYTES + 3 * WSLAB;
     static constexpr int nh(int tap) {                     // halo pieces issued inside tap `tap` (0..8; taps -1 / -2 = taps 8 / 7 of the step before)
         const int t = tap < 0 ? tap + 9 : tap;
@@ -85,9 +90,9 @@ struct Geo {
 
 // per-thread state of the K walk (a struct handed to the tap template below: the tap index has to be a compile-time constant for the
 // counted waits, and clang does not capture locals for asm operands inside generic lambdas)
-template <int NJ, int MI, int TH, int TW>
+template <int NJ, int MI, int TH, int TW, int NW>
 struct State {
-    using G = Geo<NJ, MI, TH, TW>;
+    using G = Geo<NJ, MI, TH, TW, NW>;
     const char* w;                 // weight base (bytes)
     char* smem;
     unsigned hoff[G::PPW];         // per-lane source offsets of this wave's halo pieces (0xffffffff: outside the image)
@@ -97,22 +102,25 @@ struct State {
     int pbase[MI];                 // halo position of m-tile i under tap (0, 0)
     int C, nslice, nstep, ntap, l4;
     f32x4 acc[MI][NJ];
+#if HN_ABLATE & 4
+    bf16x8_t wf_keep[NJ], xf_keep[MI];
+#endif
 };
 
 // the weights of tap `tap` of step (dt, cs) into slab (global tap index) % 3 = tap % 3 (a step has 9 taps)
-template <int NJ, int MI, int TH, int TW>
-__device__ __forceinline__ void stage_w(State<NJ, MI, TH, TW>& s, int dt, int cs, int tap) {
-    using G = Geo<NJ, MI, TH, TW>;
+template <int NJ, int MI, int TH, int TW, int NW>
+__device__ __forceinline__ void stage_w(State<NJ, MI, TH, TW, NW>& s, int dt, int cs, int tap) {
+    using G = Geo<NJ, MI, TH, TW, NW>;
     const char* src = s.w + ((int64_t)(dt * 9 + tap) * s.C + cs * 32) * 2;
     const unsigned dst = s.lds_w + (unsigned)(tap % 3) * G::WSLAB;
 #pragma unroll
-    for (int q = 0; q < G::NSW; ++q) HN_DMA(s.woff[q], src, dst + q * 4096);
+    for (int q = 0; q < G::NSW; ++q) HN_DMA(s.woff[q], src, dst + q * (NW * 1024));
 }
 
-template <int TAP, int NJ, int MI, int TH, int TW>
-__device__ __forceinline__ void tap_body(State<NJ, MI, TH, TW>& s, int step, bool more, int dt, int cs, int dtn, int csn, const i32x4& srdn,
+template <int TAP, int NJ, int MI, int TH, int TW, int NW>
+__device__ __forceinline__ void tap_body(State<NJ, MI, TH, TW, NW>& s, int step, bool more, int dt, int cs, int dtn, int csn, const i32x4& srdn,
                                          const char* hb) {
-    using G = Geo<NJ, MI, TH, TW>;
+    using G = Geo<NJ, MI, TH, TW, NW>;
     const int g = step * 9 + TAP;
     const unsigned soffn = (unsigned)csn * 64u;
     // slab g has landed and is visible, every wave is done with slab g - 1 (and, at tap 0, with the other halo buffer).
@@ -123,30 +131,40 @@ __device__ __forceinline__ void tap_body(State<NJ, MI, TH, TW>& s, int step, boo
     else if (more) wait_bar<G::NSW + G::nh(0)>();                    // first step, tap 1
     else if (g + 1 < s.ntap) wait_bar<G::NSW>();
     else wait_bar<0>();
-    if constexpr (TAP + 2 < 9) stage_w(s, dt, cs, TAP + 2);
-    else if (more) stage_w(s, dtn, csn, TAP + 2 - 9);
-    if (more) {
+    if constexpr (!(HN_ABLATE & 1)) {
+        if constexpr (TAP + 2 < 9) stage_w(s, dt, cs, TAP + 2);
+        else if (more) stage_w(s, dtn, csn, TAP + 2 - 9);
+    }
+    if (more && !(HN_ABLATE & 1)) {
 #pragma unroll
         for (int j = TAP * G::HPT; j < (TAP + 1) * G::HPT; ++j)
-            if (TAP < 8 && j < G::PPW) HN_DMAB(s.hoff[j], srdn, soffn, s.lds_h + (unsigned)((step + 1) & 1) * G::HALO_BYTES + j * 4096);
+            if (TAP < 8 && j < G::PPW) HN_DMAB(s.hoff[j], srdn, soffn, s.lds_h + (unsigned)((step + 1) & 1) * G::HALO_BYTES + j * (NW * 1024));
     }
     constexpr int dh = TAP / 3, dw = TAP % 3;
     const char* wb = s.smem + 2 * G::HALO_BYTES + (TAP % 3) * G::WSLAB + s.wfrag;
+#if HN_ABLATE & 4
+    bf16x8_t (&wf)[NJ] = s.wf_keep;
+    bf16x8_t (&xf)[MI] = s.xf_keep;
+    if constexpr (TAP == 0) {
+#else
     bf16x8_t wf[NJ], xf[MI];
+    {
+#endif
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) wf[j] = *reinterpret_cast<const bf16x8_t*>(wb + j * 1024);
+        for (int j = 0; j < NJ; ++j) wf[j] = *reinterpret_cast<const bf16x8_t*>(wb + j * 1024);
 #pragma unroll
-    for (int i = 0; i < MI; ++i) {
-        const int pos = s.pbase[i] + dh * G::HC + dw;
-        xf[i] = *reinterpret_cast<const bf16x8_t*>(hb + (unsigned)pos * 64u + (unsigned)((s.l4 ^ ((pos >> 1) & 2)) << 4));
+        for (int i = 0; i < MI; ++i) {
+            const int pos = s.pbase[i] + dh * G::HC + dw;
+            xf[i] = *reinterpret_cast<const bf16x8_t*>(hb + (unsigned)pos * 64u + (unsigned)((s.l4 ^ ((pos >> 1) & 2)) << 4));
+        }
     }
 #pragma unroll
     for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < NJ; ++j) s.acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf[i], s.acc[i][j], 0, 0, 0);
 }
-template <int TAP, int NJ, int MI, int TH, int TW>
-__device__ __forceinline__ void run_taps(State<NJ, MI, TH, TW>& s, int step, bool more, int dt, int cs, int dtn, int csn, const i32x4& srdn,
+template <int TAP, int NJ, int MI, int TH, int TW, int NW>
+__device__ __forceinline__ void run_taps(State<NJ, MI, TH, TW, NW>& s, int step, bool more, int dt, int cs, int dtn, int csn, const i32x4& srdn,
                                          const char* hb) {
     if constexpr (TAP < 9) {
         tap_body<TAP>(s, step, more, dt, cs, dtn, csn, srdn, hb);
@@ -154,9 +172,9 @@ __device__ __forceinline__ void run_taps(State<NJ, MI, TH, TW>& s, int step, boo
     }
 }
 
-template <int NJ, int MI, int TH, int TW, bool ADD>
-__global__ __launch_bounds__(256, 1) void conv_halo_n_kernel(Params p) {
-    using G = Geo<NJ, MI, TH, TW>;
+template <int NJ, int MI, int TH, int TW, int NW, bool ADD>
+__global__ __launch_bounds__(NW * 64, NW / 4) void conv_halo_n_kernel(Params p) {
+    using G = Geo<NJ, MI, TH, TW, NW>;
     __shared__ __attribute__((aligned(16))) char smem[G::LDS];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -171,7 +189,7 @@ __global__ __launch_bounds__(256, 1) void conv_halo_n_kernel(Params p) {
     const int h0 = th * TH, w0 = tw * TW;
     const unsigned ldc2 = (unsigned)p.ldc * 2u;
 
-    State<NJ, MI, TH, TW> s;
+    State<NJ, MI, TH, TW, NW> s;
     s.w = reinterpret_cast<const char*>(p.w);
     s.smem = smem;
     s.C = p.C;
@@ -179,7 +197,7 @@ __global__ __launch_bounds__(256, 1) void conv_halo_n_kernel(Params p) {
     // ---- halo pieces of this wave: piece j covers halo positions 16 (4 j + wave) + (lane >> 2); slot lane & 3 holds chunk slot ^ ((pos >> 1) & 2)
 #pragma unroll
     for (int j = 0; j < G::PPW; ++j) {
-        const int pos = 16 * (4 * j + wave) + (lane >> 2);
+        const int pos = 16 * (NW * j + wave) + (lane >> 2);
         const int r = pos / G::HC, c = pos - r * G::HC;
         const int hi = h0 - 1 + r, wi = w0 - 1 + c;
         const bool ok = pos < G::NPOS && hi >= 0 && hi < p.H && wi >= 0 && wi < p.W;
@@ -188,7 +206,7 @@ __global__ __launch_bounds__(256, 1) void conv_halo_n_kernel(Params p) {
     // ---- weight pieces of this wave: piece q = n-tile 4 q + wave (rows beyond cout read row cout - 1: their accumulator rows are never stored)
 #pragma unroll
     for (int q = 0; q < G::NSW; ++q) {
-        const int row = 16 * (4 * q + wave) + (lane >> 2);
+        const int row = 16 * (NW * q + wave) + (lane >> 2);
         s.woff[q] = (unsigned)min(row, p.cout - 1) * (unsigned)p.ldw * 2u + (unsigned)(((lane & 3) ^ ((row >> 1) & 2)) << 4);
     }
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
@@ -214,7 +232,7 @@ __global__ __launch_bounds__(256, 1) void conv_halo_n_kernel(Params p) {
     {
         const i32x4 srd0 = frame_srd(p, to - p.pt);
 #pragma unroll
-        for (int j = 0; j < G::PPW; ++j) HN_DMAB(s.hoff[j], srd0, 0u, s.lds_h + j * 4096);
+        for (int j = 0; j < G::PPW; ++j) HN_DMAB(s.hoff[j], srd0, 0u, s.lds_h + j * (NW * 1024));
         stage_w(s, 0, 0, 0);
         stage_w(s, 0, 0, 1);
     }
@@ -284,14 +302,14 @@ inline bool applies(int64_t Cin, int64_t Cout, int kt, int kh, int kw, int st, i
     return Ho * Wo >= 16 * 1024;            // >= 32 (96 channels) / 64 (160) tiles per frame; smaller frames stay on the GEMM kernels
 }
 
-template <int NJ, int MI, int TH, int TW>
+template <int NJ, int MI, int TH, int TW, int NW>
 inline int launch_inst(Params hp, int64_t To, int64_t Ho, int64_t Wo, bool add, hipStream_t s) {
     hp.tiles_w = (int)((Wo + TW - 1) / TW);
     hp.tiles_h = (int)((Ho + TH - 1) / TH);
     const int64_t nt = To * hp.tiles_h * hp.tiles_w;
     if (nt >= (1ll << 31)) return -1;
-    if (add) hipLaunchKernelGGL((conv_halo_n_kernel<NJ, MI, TH, TW, true>), dim3((unsigned)nt), dim3(256), 0, s, hp);
-    else hipLaunchKernelGGL((conv_halo_n_kernel<NJ, MI, TH, TW, false>), dim3((unsigned)nt), dim3(256), 0, s, hp);
+    if (add) hipLaunchKernelGGL((conv_halo_n_kernel<NJ, MI, TH, TW, NW, true>), dim3((unsigned)nt), dim3(NW * 64), 0, s, hp);
+    else hipLaunchKernelGGL((conv_halo_n_kernel<NJ, MI, TH, TW, NW, false>), dim3((unsigned)nt), dim3(NW * 64), 0, s, hp);
     return 0;
 }
 
