@@ -423,3 +423,46 @@ def test_conv_halo_n_96_and_160_channel_levels_vs_torch(C, T, H, W, with_cache):
     V.conv3d_cl(cl(x), cl(cache) if with_cache else None, pack_w(w), b.to(DEV), C, (3, 3, 3), (1, 1, 1), (2, 1, 1), False, out2,
                 V.EPI_ADD, add=cl(skip), zero_page=zero_page())
     assert torch.equal(out, out2)
+
+
+@pytest.mark.parametrize("with_cache,H,W", [(True, 136, 128), (False, 130, 150)])
+def test_conv_halo_n_head_96_to_4_channels_vs_torch(with_cache, H, W):
+    """the Wan2.1 decoder's head (wan/modules/vae.py:466-468: RMS_norm, SiLU, CausalConv3d(96, 3, 3, padding=1)) — 4 (3 + pad) output channels in
+    an 8-channel row — on conv_halo_n_kernel<1, ...>: until r6 a 128-wide N tile of the generic-loader GEMM kernel (14 ms per 32 frames)."""
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    Cin, Cout, T = 96, 4, 2
+    x = rnd(Cin, T, H, W, seed=51).bfloat16().float()
+    cache = rnd(Cin, 2, H, W, seed=52).bfloat16().float() if with_cache else None
+    w = (rnd(Cout, Cin, 3, 3, 3, seed=53) * (27 * Cin) ** -0.5).bfloat16().float()
+    b = rnd(Cout, seed=54) * 0.1
+    xin = torch.cat([cache, x], dim=1) if with_cache else F.pad(x, (0, 0, 0, 0, 2, 0))
+    want = F.conv3d(F.pad(xin.unsqueeze(0), (1, 1, 1, 1)), w, b)[0]
+    out = torch.full((T, H, W, 8), 7.0, dtype=torch.bfloat16, device=DEV)
+    V.conv3d_cl(cl(x), cl(cache) if with_cache else None, pack_w(w), b.to(DEV), Cout, (3, 3, 3), (1, 1, 1), (2, 1, 1), False, out,
+                V.EPI_BF16, zero_page=zero_page())
+    got = ncthw(out)
+    assert rel_l2(got[:Cout], want) < 5e-3
+    assert (got[Cout:] == 7.0).all()                                 # the channel padding of a row is not written
+    for sl in ((slice(None, Cout), 0), (slice(None, Cout), slice(None), 0), (slice(None, Cout), slice(None), -1),
+               (slice(None, Cout), slice(None), slice(None), 0), (slice(None, Cout), slice(None), slice(None), -1)):
+        assert rel_l2(got[sl], want[(slice(None),) + sl[1:]]) < 5e-3
+
+
+@pytest.mark.parametrize("H,W", [(68, 64), (65, 75)])
+def test_conv_halo_n_folded_upsample_192_to_96_vs_torch(H, W):
+    """the 192 -> 96 channel convolution behind the nearest-exact 2x upsample of the Wan2.1 decoder's last level (wan/modules/vae.py:114-128,
+    Resample 'upsample2d' / 'upsample3d'): the halo is staged at the INPUT resolution, the upsample is index arithmetic in the fragment reads."""
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    C, Co, T = 192, 96, 2
+    x = rnd(C, T, H, W, seed=61).bfloat16().float()
+    w = (rnd(Co, C, 3, 3, seed=62) * (9 * C) ** -0.5).bfloat16().float()
+    b = rnd(Co, seed=63) * 0.1
+    up = F.interpolate(x.permute(1, 0, 2, 3), scale_factor=(2.0, 2.0), mode="nearest-exact")
+    want = F.conv2d(up, w, b, padding=1).permute(1, 0, 2, 3)
+    out = torch.empty(T, 2 * H, 2 * W, Co, dtype=torch.bfloat16, device=DEV)
+    V.conv3d_cl(cl(x), None, pack_w(w.unsqueeze(2)), b.to(DEV), Co, (1, 3, 3), (1, 1, 1), (0, 1, 1), True, out, V.EPI_BF16, zero_page=zero_page())
+    got = ncthw(out)
+    assert rel_l2(got, want) < 5e-3, rel_l2(got, want)
+    for sl in ((slice(None), slice(None), 0), (slice(None), slice(None), -1), (slice(None), slice(None), slice(None), 0),
+               (slice(None), slice(None), slice(None), -1), (slice(None), slice(None), 1), (slice(None), slice(None), slice(None), 1)):
+        assert rel_l2(got[sl], want[sl]) < 5e-3, sl

@@ -30,6 +30,12 @@ def main():
         if m.sum():
             print(f"  point {s}: {m.sum()} workgroups, +{us((v - t0)[m].mean()):.2f} us after entry (min {us((v - t0)[m].min()):.2f}, max {us((v - t0)[m].max()):.2f}); "
                   f"{us((t2 - v)[m].mean()):.2f} us before the end")
+    # segments between successive points (K loop done = 1, then 3, 4, 5, 6 where the kernel set them, then the end = 2)
+    order = [1] + [k for k in range(3, 7) if (done & (t[:, k].astype(np.int64) >= t0)).sum() == done.sum()] + [2]
+    if len(order) > 2:
+        for a, b in zip(order[:-1], order[1:]):
+            d = (t[:, b].astype(np.int64) - t[:, a].astype(np.int64))[done]
+            print(f"  segment {a} -> {b}: mean {us(d.mean()):.2f}  p10 {us(np.percentile(d, 10)):.2f}  p50 {us(np.median(d)):.2f}  p90 {us(np.percentile(d, 90)):.2f}  max {us(d.max()):.2f} us")
     busy_tot, gap_tot, tail_tot, head_tot, ngap = 0, 0, 0, 0, 0
     per_x = {}
     for c in np.unique(cu):

@@ -266,15 +266,19 @@ extern "C" int yume_conv3d_cl(const void* x, const void* cache, int64_t ldc, int
         static const bool log_on = [] { const char* v = getenv("YUME_CONV_LOG"); return v && atoi(v) != 0; }();
         if (log_on) fprintf(stderr, "[conv3d_cl] halo_n M=%lld Cin=%lld Cout=%lld k=%dx%dx%d\n", (long long)M, (long long)Cin, (long long)Cout, kt, kh, kw);
         const bool addep = epi == YUME_CONV_EPI_ADD;
-        // 96 channels: two waves per SIMD (8 waves x 4 m-tiles) measured 3-5 % ahead of one (4 x 8): 1.04-1.10 vs 1.01-1.05 PF; 160 channels:
-        // the same either way (1.14 PF), one wave per SIMD kept (profiles/r6_conv_halo_n_ablations.md). YUME_CONV_HALO_NW=4|8 forces one form (A/B)
-        static const int nw = [] { const char* v = getenv("YUME_CONV_HALO_NW"); return v ? atoi(v) : 0; }();
+        // 96 channels: two waves per SIMD (8 waves x 4 m-tiles of one workgroup; measured 3-5 % ahead of 4 waves x 8 m-tiles in the first build,
+        // whose unrolled tap loop no longer fits the register file without scratch traffic: not instantiated); 160 channels / the 16-channel head:
+        // one wave per SIMD (profiles/r6_conv_halo_n_ablations.log)
         int rc;
-        if (conv_halo_n::instance(Cin, Cout) == 96)
-            rc = nw == 4 ? conv_halo_n::launch_inst<6, 8, 8, 64, 4>(hp, To, Ho, Wo, addep, s) : conv_halo_n::launch_inst<6, 4, 8, 64, 8>(hp, To, Ho, Wo, addep, s);
+        if (ups)
+            rc = addep ? -2 : conv_halo_n::launch_inst<6, 4, 8, 64, 8, true>(hp, To, Ho, Wo, false, s);
+        else if (conv_halo_n::instance(Cin, Cout) == 16)
+            rc = conv_halo_n::launch_inst<1, 8, 8, 64, 4>(hp, To, Ho, Wo, addep, s);
+        else if (conv_halo_n::instance(Cin, Cout) == 96)
+            rc = conv_halo_n::launch_inst<6, 4, 8, 64, 8>(hp, To, Ho, Wo, addep, s);
         else
-            rc = nw == 8 ? conv_halo_n::launch_inst<10, 2, 4, 64, 8>(hp, To, Ho, Wo, addep, s) : conv_halo_n::launch_inst<10, 4, 4, 64, 4>(hp, To, Ho, Wo, addep, s);
-        YUME_REQUIRE(rc == 0, "conv3d_cl: too many tiles");
+            rc = conv_halo_n::launch_inst<10, 4, 4, 64, 4>(hp, To, Ho, Wo, addep, s);
+        YUME_REQUIRE(rc == 0, "conv3d_cl: too many tiles (or an upsample convolution with a shortcut)");
         YUME_CHECK_LAUNCH("conv3d_cl");
         return YUME_OK;
     }

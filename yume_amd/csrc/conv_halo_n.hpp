@@ -36,7 +36,7 @@ struct Params {
     unsigned short* out;           // [To, H, W, ldo]
     const unsigned short* add;     // EPI ADD: [To, H, W, ldadd] or nullptr
     int64_t ldc, ldw, ldo, ldadd;
-    int Tin, H, W, C, To, cout, kt, pt;
+    int Tin, H, W, C, To, cout, kt, pt;      // H, W: the INPUT frame (the output frame is 2H x 2W with the folded nearest-2x upsample)
     int tiles_w, tiles_h;
 };
 
@@ -55,261 +55,275 @@ __device__ __forceinline__ i32x4 frame_srd(const Params& p, int ti) {
 
 #define HN_DMAB(voff, srd, soff, lds) \
     asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds" ::"v"(voff), "s"(srd), "s"(soff), "s"(lds) : "memory")
-#define HN_DMA(voff, sbase, lds) \
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds) : "memory")
 
 #ifndef HN_ABLATE
-#define HN_ABLATE 0       // experiments only (timing, wrong results): 1 = no DMA inside the loop, 2 = no waits / barriers, 4 = fragments read at tap 0 of a step only
+#define HN_ABLATE 0       // experiments only (timing, wrong results): 1 = no DMA inside the loop, 2 = no waits / barriers, 4 = no fragment reads behind a tile's first tap
 #endif
 template <int N>
-__device__ __forceinline__ void wait_bar() {
-    if constexpr (HN_ABLATE & 2) return;       // everything but the last N vector-memory operations of this wave has landed; all LDS reads are back
+__device__ __forceinline__ void wait_bar() {       // everything but the last N vector-memory operations of this wave has landed; all LDS reads are back
+    if constexpr (HN_ABLATE & 2) return;
     asm volatile("s_waitcnt vmcnt(%c0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory");
 }
 
-template <int NJ, int MI, int TH, int TW, int NW>
+template <int NJ, int MI, int TH, int TW, int NW, bool UPS = false>
 struct Geo {
     static_assert(NW == 4 || NW == 8, "one or two waves per SIMD");
     static_assert(TW % 16 == 0 && (TH * TW) / 16 == NW * MI, "NW waves x MI m-tiles of 16 columns cover the TH x TW region");
+    static_assert(!UPS || (TH % 2 == 0 && TW % 2 == 0), "an upsampled tile starts on an even row / column");
     static constexpr int MTR = TW / 16;                    // m-tiles per row
-    static constexpr int HR = TH + 2, HC = TW + 2, NPOS = HR * HC;
+    // UPS: the convolution reads the nearest-2x upsampled view of its input (nn.Upsample folded in, wan/modules/vae.py:114-128): the halo is
+    // the INPUT region (TH/2 + 2) x (TW/2 + 2) under the TH x TW output tile, output (2a+e, 2b+f) under tap (dh, dw) reads input row
+    // (2a + e + dh - 1) >> 1, column (2b + f + dw - 1) >> 1
+    static constexpr int HR = (UPS ? TH / 2 : TH) + 2, HC = (UPS ? TW / 2 : TW) + 2, NPOS = HR * HC;
     static constexpr int NPIECE = (NPOS + 15) / 16;        // pieces of 16 positions x 64 B
     static constexpr int PPW = (NPIECE + NW - 1) / NW;     // halo pieces per wave and step
-    static constexpr int HALO_BYTES = PPW * NW * 1024;
-    static constexpr int HPT = (PPW + 7) / 8;              // halo pieces issued per tap (taps 0..7 of the step before)
+    static constexpr int HPT = (PPW + 7) / 8;              // halo pieces issued per tap (taps 0..7 of the step before; the surplus slots are dummies)
+    static constexpr int HALO_BYTES = (PPW + 1) * NW * 1024;   // (+ one piece slot per wave where the dummy pieces' zeros land)
     static constexpr int NSW = (NJ + NW - 1) / NW;         // weight pieces (16 rows x 64 B = one n-tile) per wave and tap
     static constexpr int WSLAB = NSW * NW * 1024;
     static constexpr int LDS = 2 * HALO_BYTES + 3 * WSLAB;
-    static constexpr int nh(int tap) {                     // halo pieces issued inside tap `tap` (0..8; taps -1 / -2 = taps 8 / 7 of the step before)
-        const int t = tap < 0 ? tap + 9 : tap;
-        int n = 0;
-        for (int j = t * HPT; j < (t + 1) * HPT; ++j) n += (t < 8 && j < PPW) ? 1 : 0;
-        return n;
-    }
+    // EVERY tap issues exactly NSW weight pieces and HPT halo pieces, real or dummy (all lanes out of the descriptor's range: nothing is
+    // fetched, zeros land in LDS where nobody reads). Behind the slab a tap waits for come [halo of tap - 2] slab + 1 [halo of tap - 1]:
+    static constexpr int KWAIT = 2 * HPT + NSW;
 };
 
-// per-thread state of the K walk (a struct handed to the tap template below: the tap index has to be a compile-time constant for the
-// counted waits, and clang does not capture locals for asm operands inside generic lambdas)
-template <int NJ, int MI, int TH, int TW, int NW>
-struct State {
-    using G = Geo<NJ, MI, TH, TW, NW>;
-    const char* w;                 // weight base (bytes)
-    char* smem;
-    unsigned hoff[G::PPW];         // per-lane source offsets of this wave's halo pieces (0xffffffff: outside the image)
-    unsigned woff[G::NSW];         // ... of its weight pieces
-    unsigned lds_h, lds_w;         // LDS byte addresses of this wave's 1 KiB piece slot in halo buffer 0 / weight slab 0
-    unsigned wfrag;                // weight fragment offset inside an n-tile's 1 KiB
-    int pbase[MI];                 // halo position of m-tile i under tap (0, 0)
-    int C, nslice, nstep, ntap, l4;
-    f32x4 acc[MI][NJ];
-#if HN_ABLATE & 4
-    bf16x8_t wf_keep[NJ], xf_keep[MI];
-#endif
-};
-
-// the weights of tap `tap` of step (dt, cs) into slab (global tap index) % 3 = tap % 3 (a step has 9 taps)
-template <int NJ, int MI, int TH, int TW, int NW>
-__device__ __forceinline__ void stage_w(State<NJ, MI, TH, TW, NW>& s, int dt, int cs, int tap) {
-    using G = Geo<NJ, MI, TH, TW, NW>;
-    const char* src = s.w + ((int64_t)(dt * 9 + tap) * s.C + cs * 32) * 2;
-    const unsigned dst = s.lds_w + (unsigned)(tap % 3) * G::WSLAB;
-#pragma unroll
-    for (int q = 0; q < G::NSW; ++q) HN_DMA(s.woff[q], src, dst + q * (NW * 1024));
-}
-
-template <int TAP, int NJ, int MI, int TH, int TW, int NW>
-__device__ __forceinline__ void tap_body(State<NJ, MI, TH, TW, NW>& s, int step, bool more, int dt, int cs, int dtn, int csn, const i32x4& srdn,
-                                         const char* hb) {
-    using G = Geo<NJ, MI, TH, TW, NW>;
-    const int g = step * 9 + TAP;
-    const unsigned soffn = (unsigned)csn * 64u;
-    // slab g has landed and is visible, every wave is done with slab g - 1 (and, at tap 0, with the other halo buffer).
-    // Issued behind slab g: [halo(tap - 2)] slab g + 1 [halo(tap - 1)] — counted exactly where all of them exist, else more is awaited
-    if (g == 0) wait_bar<G::NSW>();                                  // prologue: halo 0 and slab 0 (slab 1 may stay in flight)
-    else if (more && step > 0) wait_bar<G::nh(TAP - 2) + G::NSW + G::nh(TAP - 1)>();
-    else if (more && TAP >= 2) wait_bar<G::nh(TAP - 2) + G::NSW + G::nh(TAP - 1)>();   // first step: no halo pieces were issued before its tap 0
-    else if (more) wait_bar<G::NSW + G::nh(0)>();                    // first step, tap 1
-    else if (g + 1 < s.ntap) wait_bar<G::NSW>();
-    else wait_bar<0>();
-    if constexpr (!(HN_ABLATE & 1)) {
-        if constexpr (TAP + 2 < 9) stage_w(s, dt, cs, TAP + 2);
-        else if (more) stage_w(s, dtn, csn, TAP + 2 - 9);
-    }
-    if (more && !(HN_ABLATE & 1)) {
-#pragma unroll
-        for (int j = TAP * G::HPT; j < (TAP + 1) * G::HPT; ++j)
-            if (TAP < 8 && j < G::PPW) HN_DMAB(s.hoff[j], srdn, soffn, s.lds_h + (unsigned)((step + 1) & 1) * G::HALO_BYTES + j * (NW * 1024));
-    }
-    constexpr int dh = TAP / 3, dw = TAP % 3;
-    const char* wb = s.smem + 2 * G::HALO_BYTES + (TAP % 3) * G::WSLAB + s.wfrag;
-#if HN_ABLATE & 4
-    bf16x8_t (&wf)[NJ] = s.wf_keep;
-    bf16x8_t (&xf)[MI] = s.xf_keep;
-    if constexpr (TAP == 0) {
-#else
-    bf16x8_t wf[NJ], xf[MI];
-    {
-#endif
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) wf[j] = *reinterpret_cast<const bf16x8_t*>(wb + j * 1024);
-#pragma unroll
-        for (int i = 0; i < MI; ++i) {
-            const int pos = s.pbase[i] + dh * G::HC + dw;
-            xf[i] = *reinterpret_cast<const bf16x8_t*>(hb + (unsigned)pos * 64u + (unsigned)((s.l4 ^ ((pos >> 1) & 2)) << 4));
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < MI; ++i)
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) s.acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf[i], s.acc[i][j], 0, 0, 0);
-}
-template <int TAP, int NJ, int MI, int TH, int TW, int NW>
-__device__ __forceinline__ void run_taps(State<NJ, MI, TH, TW, NW>& s, int step, bool more, int dt, int cs, int dtn, int csn, const i32x4& srdn,
-                                         const char* hb) {
-    if constexpr (TAP < 9) {
-        tap_body<TAP>(s, step, more, dt, cs, dtn, csn, srdn, hb);
-        run_taps<TAP + 1>(s, step, more, dt, cs, dtn, csn, srdn, hb);
-    }
-}
-
-template <int NJ, int MI, int TH, int TW, int NW, bool ADD>
+// (r6, third build) The tap loop is a RUN-TIME loop: the first two builds unrolled the 9 taps of a step (compile-time wait counts) and the
+// compiler, pipelining across them, ran out of registers (44-110 VGPRs to scratch in the persistent form — and scratch traffic counts in vmcnt,
+// which the counted waits below cannot tolerate). With uniform issue counts per tap one wait immediate serves every tap.
+template <int NJ, int MI, int TH, int TW, int NW, bool ADD, bool UPS = false>
 __global__ __launch_bounds__(NW * 64, NW / 4) void conv_halo_n_kernel(Params p) {
-    using G = Geo<NJ, MI, TH, TW, NW>;
+    using G = Geo<NJ, MI, TH, TW, NW, UPS>;
     __shared__ __attribute__((aligned(16))) char smem[G::LDS];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l15 = lane & 15, l4 = lane >> 4;
-    // tile: XCD x walks its own contiguous chunk of the (frame, row band, column band) order
+    // tiles: XCD x walks its own contiguous chunk of the (frame, row band, column band) order, its g workgroups interleaved in it. PERSISTENT:
+    // a tile is ~40 us of MFMAs between a prologue that waits for its first halo and an epilogue of 8-byte stores, and with one workgroup per
+    // CU nothing overlapped them (with every DMA, wait and fragment read removed the one-tile-per-workgroup build ran at 1.5 PF,
+    // profiles/r6_conv_halo_n_ablations.log). During the last step of a tile the workgroup stages the first halo and the first two weight slabs
+    // of its NEXT tile.
     int start, count;
     const int ntile = p.To * p.tiles_h * p.tiles_w;
     xcd_chunk(ntile, blockIdx.x & 7, start, count);
-    const int tile = start + (blockIdx.x >> 3);
-    const int tw = tile % p.tiles_w, th = (tile / p.tiles_w) % p.tiles_h, to = tile / (p.tiles_w * p.tiles_h);
-    const int h0 = th * TH, w0 = tw * TW;
+    const int gwg = (int)(gridDim.x >> 3), idx = (int)(blockIdx.x >> 3);
+    if (idx >= count) return;                                        // (workgroup-uniform)
+    int tile = start + idx;
+    const int tend = start + count;
+    auto coords = [&](int t, int& to, int& h0, int& w0) {
+        const int tw = t % p.tiles_w, th = (t / p.tiles_w) % p.tiles_h;
+        to = t / (p.tiles_w * p.tiles_h);
+        h0 = th * TH;
+        w0 = tw * TW;
+    };
+    int to, h0, w0;
+    coords(tile, to, h0, w0);
     const unsigned ldc2 = (unsigned)p.ldc * 2u;
+    const int nslice = p.C / 32, nstep = p.kt * nslice;
 
-    State<NJ, MI, TH, TW, NW> s;
-    s.w = reinterpret_cast<const char*>(p.w);
-    s.smem = smem;
-    s.C = p.C;
-    s.l4 = l4;
-    // ---- halo pieces of this wave: piece j covers halo positions 16 (4 j + wave) + (lane >> 2); slot lane & 3 holds chunk slot ^ ((pos >> 1) & 2)
-#pragma unroll
-    for (int j = 0; j < G::PPW; ++j) {
+    // source offset of this lane in halo piece j (positions 16 (NW j + wave) + (lane >> 2)) of the tile at (hh, ww); slot lane & 3 holds chunk
+    // slot ^ ((pos >> 1) & 2); outside the image / beyond the halo: out of range (zeros)
+    auto halo_off = [&](int j, int hh, int ww) -> unsigned {
         const int pos = 16 * (NW * j + wave) + (lane >> 2);
         const int r = pos / G::HC, c = pos - r * G::HC;
-        const int hi = h0 - 1 + r, wi = w0 - 1 + c;
+        const int hi = (UPS ? hh / 2 : hh) - 1 + r, wi = (UPS ? ww / 2 : ww) - 1 + c;
         const bool ok = pos < G::NPOS && hi >= 0 && hi < p.H && wi >= 0 && wi < p.W;
-        s.hoff[j] = ok ? (unsigned)(hi * p.W + wi) * ldc2 + (unsigned)(((lane & 3) ^ ((pos >> 1) & 2)) << 4) : 0xffffffffu;
-    }
-    // ---- weight pieces of this wave: piece q = n-tile 4 q + wave (rows beyond cout read row cout - 1: their accumulator rows are never stored)
+        return ok ? (unsigned)(hi * p.W + wi) * ldc2 + (unsigned)(((lane & 3) ^ ((pos >> 1) & 2)) << 4) : 0xffffffffu;
+    };
+    // weight pieces of this wave: piece q = n-tile NW q + wave; n-tiles that do not exist are dummies
+    unsigned woff[G::NSW];
 #pragma unroll
     for (int q = 0; q < G::NSW; ++q) {
         const int row = 16 * (NW * q + wave) + (lane >> 2);
-        s.woff[q] = (unsigned)min(row, p.cout - 1) * (unsigned)p.ldw * 2u + (unsigned)(((lane & 3) ^ ((row >> 1) & 2)) << 4);
+        woff[q] = row < p.cout ? (unsigned)row * (unsigned)p.ldw * 2u + (unsigned)(((lane & 3) ^ ((row >> 1) & 2)) << 4) : 0xffffffffu;
+    }
+    i32x4 wsrd;                                                         // the weight array as a raw buffer (rows 0 .. cout - 1)
+    {
+        const uint64_t b = (uint64_t)(uintptr_t)p.w;
+        wsrd[0] = (int)(unsigned)(b & 0xffffffffu);
+        wsrd[1] = (int)(unsigned)((b >> 32) & 0xffffu);
+        wsrd[2] = 0x7fffffff;
+        wsrd[3] = 0x00020000;
     }
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
-    s.lds_h = lds0 + wave * 1024;
-    s.lds_w = lds0 + 2 * G::HALO_BYTES + wave * 1024;
-    s.nslice = p.C / 32;
-    s.nstep = p.kt * s.nslice;
-    s.ntap = s.nstep * 9;
-    // ---- fragment addresses. Weights: n-tile j, row l15, chunk l4 of the slab. Halo: m-tile i of this wave = row (wave MI + i) / MTR,
-    //      columns 16 ((wave MI + i) % MTR) + l15; under tap (dh, dw) it reads halo position (row + dh) HC + column + dw
-    s.wfrag = (unsigned)(l15 * 64 + ((l4 ^ ((l15 >> 1) & 2)) << 4));
+    const unsigned lds_h = lds0 + wave * 1024, lds_w = lds0 + 2 * G::HALO_BYTES + wave * 1024;
+    // fragment addresses. Weights: n-tile j, row l15, chunk l4 of the slab. Halo: m-tile i of this wave = row (wave MI + i) / MTR,
+    // columns 16 ((wave MI + i) % MTR) + l15; under tap (dh, dw) it reads halo position (row + dh) HC + column + dw
+    const unsigned wfrag = (unsigned)(l15 * 64 + ((l4 ^ ((l15 >> 1) & 2)) << 4));
+    int pbase[MI];                                                      // (UPS: the m-tile's output column of this lane, minus 1)
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
         const int mt = wave * MI + i;
-        s.pbase[i] = (mt / G::MTR) * G::HC + (mt % G::MTR) * 16 + l15;
+        pbase[i] = UPS ? (mt % G::MTR) * 16 + l15 - 1 : (mt / G::MTR) * G::HC + (mt % G::MTR) * 16 + l15;
     }
+    // weights of (dt, cs, tap): byte offset inside a weight row; slab of a tap = tap % 3
+    auto w_soff = [&](int dt, int cs, int tap) -> unsigned { return (unsigned)(((dt * 9 + tap) * p.C + cs * 32) * 2); };
+    auto stage_w = [&](unsigned soff, int slot, bool real) {
 #pragma unroll
-    for (int i = 0; i < MI; ++i)
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) s.acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int q = 0; q < G::NSW; ++q) HN_DMAB(real ? woff[q] : 0xffffffffu, wsrd, soff, lds_w + (unsigned)slot * G::WSLAB + q * (NW * 1024));
+    };
 
-    // ---- prologue: halo of step 0, weights of taps 0 and 1
+    // ---- prologue: halo of step 0 of the first tile (all 8 HPT piece slots), weights of taps 0 and 1
     {
         const i32x4 srd0 = frame_srd(p, to - p.pt);
 #pragma unroll
-        for (int j = 0; j < G::PPW; ++j) HN_DMAB(s.hoff[j], srd0, 0u, s.lds_h + j * (NW * 1024));
-        stage_w(s, 0, 0, 0);
-        stage_w(s, 0, 0, 1);
+        for (int j = 0; j < G::PPW; ++j) HN_DMAB(halo_off(j, h0, w0), srd0, 0u, lds_h + j * (NW * 1024));
+        stage_w(w_soff(0, 0, 0), 0, true);
+        stage_w(w_soff(0, 0, 1), 1, true);
     }
-    int dt = 0, cs = 0;
-    for (int step = 0; step < s.nstep; ++step) {
-        const bool more = step + 1 < s.nstep;                            // (uniform) a next halo to stage
-        int dtn = dt, csn = cs + 1;
-        if (csn == s.nslice) { csn = 0; ++dtn; }
-        const i32x4 srdn = frame_srd(p, to - p.pt + dtn);
-        run_taps<0>(s, step, more, dt, cs, dtn, csn, srdn, smem + (step & 1) * G::HALO_BYTES);
-        dt = dtn;
-        cs = csn;
-    }
-
-    // ---- epilogue: a lane holds channels 16 j + 4 l4 .. + 3 of position (row, column 16 m + l15) of its MI m-tiles
+    unsigned gs = 0;                                                     // steps done by this workgroup: the halo buffer of a step is gs & 1
     const int nch = 4 * l4;
+    f32x4 acc[MI][NJ];
+    for (;;) {
+        const int tnext = tile + gwg;
+        const bool has_next = tnext < tend;                              // (uniform)
+        int ton = to, h0n = h0, w0n = w0;
+        if (has_next) coords(tnext, ton, h0n, w0n);
 #pragma unroll
-    for (int i = 0; i < MI; ++i) {
-        const int mt = wave * MI + i;
-        const int ho = h0 + mt / G::MTR, wo = w0 + (mt % G::MTR) * 16 + l15;
-        if (ho >= p.H || wo >= p.W) continue;
-        const int64_t pos = ((int64_t)to * p.H + ho) * p.W + wo;
-        unsigned short* o = p.out + pos * p.ldo + nch;
-        const unsigned short* a = ADD ? p.add + pos * p.ldadd + nch : nullptr;
-        u32x2 a2[NJ];
-        if (ADD) {
+        for (int i = 0; i < MI; ++i)
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) a2[j] = (16 * j + nch < p.cout) ? *reinterpret_cast<const u32x2*>(a + 16 * j) : u32x2{0u, 0u};
-        }
+            for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        int dt = 0, cs = 0;
+        for (int step = 0; step < nstep; ++step, ++gs) {
+            const bool last = step + 1 == nstep;
+            const bool more = !last || has_next;                         // (uniform) a next halo to stage: the next step's, or the next tile's first
+            int dtn = dt, csn = cs + 1;
+            if (csn == nslice) { csn = 0; ++dtn; }
+            if (last) { dtn = 0; csn = 0; }
+            const int hh = last ? h0n : h0, ww = last ? w0n : w0;        // whose halo is staged during this step
+            const i32x4 srdn = frame_srd(p, (last ? ton : to) - p.pt + dtn);
+            const unsigned soffn = (unsigned)csn * 64u;
+            const char* hb = smem + (gs & 1u) * G::HALO_BYTES;
+            const unsigned nbuf = lds_h + ((gs + 1u) & 1u) * G::HALO_BYTES;
+            int toff = 0, dh = 0, dw = 0;                                // halo offset of the tap: dh HC + dw
+            // (written as a loop, unrolled by the compiler: the piece indices, slab slots and tap offsets become literals — the rolled form
+            // hipcc chose for one instance on its own measured 842 against 1145 TFLOP/s — while nothing is scheduled across the taps' barriers)
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-            if (16 * j + nch >= p.cout) continue;                 // whole groups of 4 channels (cout % 4 == 0)
-            f32x4 v = s.acc[i][j];
-            if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + 16 * j + nch);
-            if (ADD) {
-                v[0] += bf16_to_f32((unsigned short)(a2[j][0] & 0xffffu));
-                v[1] += bf16_to_f32((unsigned short)(a2[j][0] >> 16));
-                v[2] += bf16_to_f32((unsigned short)(a2[j][1] & 0xffffu));
-                v[3] += bf16_to_f32((unsigned short)(a2[j][1] >> 16));
+            for (int tap = 0; tap < 9; ++tap) {
+                // slab `tap` has landed and is visible, every wave is done with the slab before it (and, at tap 0, with the other halo buffer).
+                // The first tap of a tile waits for everything: its halo and first slabs were issued in front of the previous tile's epilogue
+                // stores, and loads and stores do not retire in order with each other — only vmcnt(0) is safe behind stores.
+                if (step == 0 && tap == 0) wait_bar<0>();
+                else wait_bar<G::KWAIT>();
+                if (!(HN_ABLATE & 1)) {
+                    // weights two taps ahead (this step's, the next step's, or the next tile's first two), then this tap's share of the next halo
+                    const int t2 = tap + 2;
+                    if (t2 < 9) stage_w(w_soff(dt, cs, t2), t2 % 3, true);
+                    else stage_w(w_soff(dtn, csn, t2 - 9), (t2 - 9) % 3, more);
+#pragma unroll
+                    for (int k = 0; k < G::HPT; ++k) {
+                        const int j = tap * G::HPT + k;
+                        // the LDS slot depends on the loop counters only (a piece index the step has -> its slot, else the spare slot); whether
+                        // anything is FETCHED also depends on `more` — kept out of the slot's select, which the compiler otherwise folds into the
+                        // per-lane select of the source offset and hands the asm's M0 operand a VGPR
+                        const bool exists = tap < 8 && j < G::PPW;
+                        const unsigned slot = nbuf + (unsigned)(exists ? j : G::PPW) * (NW * 1024);
+                        HN_DMAB((more && exists) ? halo_off(j, hh, ww) : 0xffffffffu, srdn, soffn, slot);
+                    }
+                }
+                const char* wb = smem + 2 * G::HALO_BYTES + (tap % 3) * G::WSLAB + wfrag;
+                bf16x8_t wf[NJ], xf[MI];
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) wf[j] = *reinterpret_cast<const bf16x8_t*>(wb + j * 1024);
+#pragma unroll
+                for (int i = 0; i < MI; ++i) {
+                    int pos = pbase[i] + toff;
+                    if constexpr (UPS) pos = ((((wave * MI + i) / G::MTR + dh - 1) >> 1) + 1) * G::HC + ((pbase[i] + dw) >> 1) + 1;
+                    xf[i] = *reinterpret_cast<const bf16x8_t*>(hb + (unsigned)pos * 64u + (unsigned)((l4 ^ ((pos >> 1) & 2)) << 4));
+                }
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf[i], acc[i][j], 0, 0, 0);
+                toff += (tap % 3 == 2) ? G::HC - 2 : 1;
+                if (++dw == 3) { dw = 0; ++dh; }
             }
-            u32x2 ov;
-            ov[0] = pack_bf16x2(v[0], v[1]);
-            ov[1] = pack_bf16x2(v[2], v[3]);
-            *reinterpret_cast<u32x2*>(o + 16 * j) = ov;
+            dt = dtn;
+            cs = csn;
         }
+
+        // ---- epilogue: a lane holds channels 16 j + 4 l4 .. + 3 of position (row, column 16 m + l15) of its MI m-tiles
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            const int mt = wave * MI + i;
+            const int ho = h0 + mt / G::MTR, wo = w0 + (mt % G::MTR) * 16 + l15;
+            const int OH = UPS ? 2 * p.H : p.H, OW = UPS ? 2 * p.W : p.W;
+            if (ho >= OH || wo >= OW) continue;
+            const int64_t pos = ((int64_t)to * OH + ho) * OW + wo;
+            unsigned short* o = p.out + pos * p.ldo + nch;
+            const unsigned short* a = ADD ? p.add + pos * p.ldadd + nch : nullptr;
+            u32x2 a2[NJ];
+            if (ADD) {
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) a2[j] = (16 * j + nch < p.cout) ? *reinterpret_cast<const u32x2*>(a + 16 * j) : u32x2{0u, 0u};
+            }
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                if (16 * j + nch >= p.cout) continue;                 // whole groups of 4 channels (cout % 4 == 0)
+                f32x4 v = acc[i][j];
+                if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + 16 * j + nch);
+                if (ADD) {
+                    v[0] += bf16_to_f32((unsigned short)(a2[j][0] & 0xffffu));
+                    v[1] += bf16_to_f32((unsigned short)(a2[j][0] >> 16));
+                    v[2] += bf16_to_f32((unsigned short)(a2[j][1] & 0xffffu));
+                    v[3] += bf16_to_f32((unsigned short)(a2[j][1] >> 16));
+                }
+                u32x2 ov;
+                ov[0] = pack_bf16x2(v[0], v[1]);
+                ov[1] = pack_bf16x2(v[2], v[3]);
+                *reinterpret_cast<u32x2*>(o + 16 * j) = ov;
+            }
+        }
+        if (!has_next) break;
+        tile = tnext;
+        to = ton;
+        h0 = h0n;
+        w0 = w0n;
     }
 }
 
 // the shapes the kernel takes (host). The rule looks at the LAYER (channels, kernel, frame size), never at the number of frames in the
 // launch: the grouped passes of a decoder and its one-latent-per-pass walk must take the same kernel for a layer (equal bits,
 // tests/test_live_fullsize_gpu.py).
-inline int instance(int64_t Cin, int64_t Cout) {
+inline int instance(int64_t Cin, int64_t Cout, int ups = 0) {
+    if (ups) return (Cin % 32 == 0 && Cout == 96) ? 96 : 0;  // the 192 -> 96 upsample convolution of the Wan2.1 decoder (37 % of a 256-wide N tile)
     if (Cin % 32 != 0 || Cin % 64 == 0) return 0;            // whole 64-wide K tiles are conv_w4's / the fast loader's
     if (Cout == 96) return 96;
     if (Cout == 160) return 160;
+    if (Cout <= 16) return 16;                               // the Wan2.1 decoder's head, 96 -> 3 (+1) channels at full resolution (conv_halo.hpp's case at Cin % 64 != 0)
     return 0;
 }
 inline bool applies(int64_t Cin, int64_t Cout, int kt, int kh, int kw, int st, int sh, int sw, int pt, int ph, int pw, int ups, int64_t Hin, int64_t Win,
                     int64_t Ho, int64_t Wo, int64_t ldc, int64_t ldo, int64_t ldw, int epi, int64_t ldadd) {
     static const bool on = [] { const char* v = getenv("YUME_CONV_HALO_N"); return !v || atoi(v) != 0; }();
-    if (!on || ups || st != 1 || sh != 1 || sw != 1 || kh != 3 || kw != 3 || ph != 1 || pw != 1) return false;
+    if (!on || st != 1 || sh != 1 || sw != 1 || kh != 3 || kw != 3 || ph != 1 || pw != 1) return false;
     if (!((kt == 3 && pt == 2) || (kt == 1 && pt == 0))) return false;
     if (epi != YUME_EPI_BF16 && epi != YUME_CONV_EPI_ADD) return false;
-    if (instance(Cin, Cout) == 0 || Ho != Hin || Wo != Win) return false;
-    if ((ldc % 8) != 0 || (ldw % 8) != 0 || (ldo % 4) != 0 || ldo < Cout || (epi == YUME_CONV_EPI_ADD && ((ldadd % 4) != 0 || ldadd < Cout))) return false;
+    if (instance(Cin, Cout, ups) == 0) return false;
+    if (ups ? (Ho != 2 * Hin || Wo != 2 * Win || kt != 1) : (Ho != Hin || Wo != Win)) return false;
+    if ((ldc % 8) != 0 || (ldw % 8) != 0 || (ldo % 4) != 0 || ldo < Cout || (Cout % 4) != 0 || (epi == YUME_CONV_EPI_ADD && ((ldadd % 4) != 0 || ldadd < Cout))) return false;
     if (Hin * Win * ldc * 2 >= 0x7fffff00ll || (Cout - 1) * ldw * 2 + 64 >= 0x7fffff00ll) return false;
     return Ho * Wo >= 16 * 1024;            // >= 32 (96 channels) / 64 (160) tiles per frame; smaller frames stay on the GEMM kernels
 }
 
-template <int NJ, int MI, int TH, int TW, int NW>
+template <int NJ, int MI, int TH, int TW, int NW, bool UPS = false>
 inline int launch_inst(Params hp, int64_t To, int64_t Ho, int64_t Wo, bool add, hipStream_t s) {
     hp.tiles_w = (int)((Wo + TW - 1) / TW);
     hp.tiles_h = (int)((Ho + TH - 1) / TH);
     const int64_t nt = To * hp.tiles_h * hp.tiles_w;
     if (nt >= (1ll << 31)) return -1;
-    if (add) hipLaunchKernelGGL((conv_halo_n_kernel<NJ, MI, TH, TW, NW, true>), dim3((unsigned)nt), dim3(NW * 64), 0, s, hp);
-    else hipLaunchKernelGGL((conv_halo_n_kernel<NJ, MI, TH, TW, NW, false>), dim3((unsigned)nt), dim3(NW * 64), 0, s, hp);
+    // persistent: one workgroup per CU (its LDS admits no second), 32 per XCD, each walking tiles idx, idx + 32, ... of its XCD's chunk
+    // (YUME_CONV_HALO_PERSIST=0: one workgroup per tile, the first build, for A/B)
+    static const bool persist = [] { const char* v = getenv("YUME_CONV_HALO_PERSIST"); return !v || atoi(v) != 0; }();
+    static const int ncu = [] {
+        int d = 0, n = 256;
+        if (hipGetDevice(&d) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, d) != hipSuccess) n = 256;
+        return n > 0 ? n : 256;
+    }();
+    const int64_t per_xcd = persist ? (ncu + 7) / 8 : (nt + 7) / 8;
+    const unsigned grid = (unsigned)(8 * ((nt + 7) / 8 < per_xcd ? (nt + 7) / 8 : per_xcd));
+    if (add) hipLaunchKernelGGL((conv_halo_n_kernel<NJ, MI, TH, TW, NW, true, UPS>), dim3(grid), dim3(NW * 64), 0, s, hp);
+    else hipLaunchKernelGGL((conv_halo_n_kernel<NJ, MI, TH, TW, NW, false, UPS>), dim3(grid), dim3(NW * 64), 0, s, hp);
     return 0;
 }
 

@@ -447,6 +447,7 @@ __device__ __forceinline__ void w4_epilogue(const Problem& p, const Epilogue& e,
             }
             issue_g(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
             issue_g(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{});
+            TRACE_STAMP(3);                                            // (trace builds) the loads of the first two row blocks are issued
             static_for<0, 8>([&](auto ii) {
                 constexpr int i = decltype(ii)::value, bf = i & 1;
                 static_for<0, 8>([&](auto jj) {
@@ -460,9 +461,13 @@ __device__ __forceinline__ void w4_epilogue(const Problem& p, const Epilogue& e,
                     issue_x(std::integral_constant<int, i + 2>{}, std::integral_constant<int, bf>{});
                     issue_g(std::integral_constant<int, i + 2>{}, std::integral_constant<int, bf>{});
                 }
-                if (i == 0) TRACE_STAMP(3);
-                if (i == 3) TRACE_STAMP(4);
+                if (i == 0) TRACE_STAMP(4);                            // first row block: loads landed, combined, its stores issued
             });
+            TRACE_STAMP(5);                                            // all eight row blocks combined, every store issued
+#ifdef YUME_TRACE
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // (trace builds only) ... and drained
+            TRACE_STAMP(6);
+#endif
             return;
         }
         static_for<0, 64>([&](auto tt) {
