@@ -38,7 +38,7 @@ extern "C" {
 /* ---- library info ------------------------------------------------------------------- */
 const char* yume_last_error(void);
 /* ABI version of this header; bumped on any signature change (yume_amd/_lib.py refuses a library that reports another one). */
-#define YUME_ABI_VERSION 7
+#define YUME_ABI_VERSION 8
 int yume_abi_version(void);
 /* name of the gfx target the kernels were compiled for ("gfx950"). */
 const char* yume_target_arch(void);
@@ -125,6 +125,22 @@ int yume_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, const
                    const float* gate, int64_t gate_stride, const int32_t* row_idx,
                    void* outT, int64_t ldt, int64_t n_split,
                    int variant, void* stream);
+
+/* Same call with caller-owned scratch for the STREAM-K TAIL of the one-wave-per-SIMD kernel (r6, ABI 8): a GEMM whose 256 x 256 tiles are
+ * not whole rounds of the chip's CUs (the block's N = 3072 projections: 444 tiles = 1.73 rounds) walks the whole rounds one tile per
+ * workgroup and cuts the tiles of the last round(s) along K over one more full round of workgroups; partial tiles meet in `workspace`
+ * (fp32, summed in a fixed order: results are run-to-run identical). workspace: yume_gemm_workspace_bytes() bytes, 16-byte aligned, ZERO
+ * when first handed over (a launch returns every flag word to zero: no memset between launches, capturable into a hipGraph); launches
+ * that share one workspace must be ordered on one stream (yume_amd/ops.py keeps one per device and stream). workspace = NULL or too
+ * small: the schedules without it (whole tiles; row split + remainder launch), i.e. exactly yume_gemm_bf16. The word behind the last
+ * flag (byte offset yume_gemm_workspace_bytes() - 64) is an error word: non-zero after a launch whose finisher timed out on a flag. */
+int64_t yume_gemm_workspace_bytes(void);
+int yume_gemm_bf16_ws(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias,
+                      int64_t M, int64_t N, int64_t K, int epi,
+                      void* out, int64_t ldo,
+                      const float* gate, int64_t gate_stride, const int32_t* row_idx,
+                      void* outT, int64_t ldt, int64_t n_split,
+                      int variant, void* workspace, int64_t workspace_bytes, void* stream);
 
 /* ---- RMSNorm over the hidden dim (+ optional 3D RoPE), in place, bf16 -----------------------
  * replaces: wan23/modules/model.py:121-137 (WanRMSNorm on q,k over the FULL hidden dim C),

@@ -16,7 +16,13 @@
 typedef int (*gemm_fn)(const void*, int64_t, const void*, int64_t, const float*, int64_t, int64_t, int64_t, int, void*, int64_t, const float*, int64_t,
                        const int32_t*, void*, int64_t, int64_t, int, void*);
 typedef const char* (*err_fn)();
+typedef int (*gemm_ws_fn)(const void*, int64_t, const void*, int64_t, const float*, int64_t, int64_t, int64_t, int, void*, int64_t, const float*, int64_t,
+                          const int32_t*, void*, int64_t, int64_t, int, void*, int64_t, void*);
+typedef int64_t (*ws_bytes_fn)();
 static gemm_fn p_gemm;
+static gemm_ws_fn p_gemm_ws;      // --sk: the stream-K entry point with a zero-initialised scratch
+static void* g_ws;
+static int64_t g_ws_bytes;
 static err_fn p_err;
 
 #define HC(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(2); } } while (0)
@@ -61,6 +67,7 @@ static int run_case(const Case& c, const std::vector<int>& variants, int reps, b
     else HC(hipMemset(dout, 0xff, M * N * osz));
     if (dt) HC(hipMemset(dt, 0, (N - nsplit) * ldt * 2));
     auto call = [&]() {
+        if (g_ws) return p_gemm_ws(da, K, dw, K, dbias, M, N, K, c.epi, dout, N, c.R > 0 ? dgate : nullptr, N, c.R > 1 ? dr : nullptr, dt, ldt, nsplit, variant, g_ws, g_ws_bytes, nullptr);
         return p_gemm(da, K, dw, K, dbias, M, N, K, c.epi, dout, N, c.R > 0 ? dgate : nullptr, N, c.R > 1 ? dr : nullptr, dt, ldt, nsplit, variant, nullptr);
     };
     int rc = call();
@@ -132,6 +139,7 @@ int main(int argc, char** argv) {
     bool timing_only = false, quick = false, expm = false;
     std::vector<int> variants = {2, 3};        // 2 = 8-wave 256x256 kernel, 3 = one-wave-per-SIMD 256x256 kernel (gemm_w4.hpp), 0 = automatic
     int reps = 2;
+    bool use_sk = false;              // --sk: yume_gemm_bf16_ws with a scratch (stream-K tail of the one-wave-per-SIMD kernel)
     const char* trace = nullptr;      // --trace file (with --one): dump the per-workgroup time stamps of an experiment build (csrc/trace.hpp)
     long long one[5] = {0, 0, 0, 0, 0};
     for (int i = 1; i < argc; ++i) {
@@ -141,6 +149,7 @@ int main(int argc, char** argv) {
         else if (!strcmp(argv[i], "--exp")) { timing_only = true; expm = true; }         // experiment builds (bf16 epilogue only): the block's shapes with a plain epilogue
         else if (!strcmp(argv[i], "--reps")) reps = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--trace")) trace = argv[++i];
+        else if (!strcmp(argv[i], "--sk")) use_sk = true;
         else if (!strcmp(argv[i], "--one")) { for (int j = 0; j < 5; ++j) one[j] = atoll(argv[++i]); timing_only = true; }      // M N K epi row_idx_tables
         else if (!strcmp(argv[i], "--variants")) {
             variants.clear();
@@ -150,6 +159,14 @@ int main(int argc, char** argv) {
     void* hnd = dlopen(lib, RTLD_NOW | RTLD_LOCAL | RTLD_DEEPBIND);
     if (!hnd) { printf("dlopen %s: %s\n", lib, dlerror()); return 2; }
     p_gemm = (gemm_fn)dlsym(hnd, "yume_gemm_bf16"); p_err = (err_fn)dlsym(hnd, "yume_last_error");
+    if (use_sk) {
+        p_gemm_ws = (gemm_ws_fn)dlsym(hnd, "yume_gemm_bf16_ws");
+        ws_bytes_fn wb = (ws_bytes_fn)dlsym(hnd, "yume_gemm_workspace_bytes");
+        if (!p_gemm_ws || !wb) { printf("--sk: the library has no yume_gemm_bf16_ws\n"); return 2; }
+        g_ws_bytes = wb();
+        HC(hipMalloc(&g_ws, g_ws_bytes));
+        HC(hipMemset(g_ws, 0, g_ws_bytes));
+    }
     const char* mode = getenv("YUME_GEMM_MODE");
     printf("library %s  YUME_GEMM_MODE=%s\n", lib, mode ? mode : "(default)");
     int fails = 0;

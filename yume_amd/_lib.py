@@ -23,6 +23,8 @@ SIGNATURES = {
     "yume_calibrate_mfma": [_L, _L, _P, _P, _P],
     "yume_adaln_modulate": [_P, _L, _L, _L, _F, _P, _P, _L, _P, _I, _P, _L, _I, _P],
     "yume_gemm_bf16": [_P, _L, _P, _L, _P, _L, _L, _L, _I, _P, _L, _P, _L, _P, _P, _L, _L, _I, _P],
+    "yume_gemm_workspace_bytes": [],
+    "yume_gemm_bf16_ws": [_P, _L, _P, _L, _P, _L, _L, _L, _I, _P, _L, _P, _L, _P, _P, _L, _L, _I, _P, _L, _P],
     "yume_rmsnorm_f32": [_P, _L, _L, _L, _F, _P, _P, _L, _P],
     "yume_gemm_bf16_batched": [_P, _L, _L, _P, _L, _L, _L, _L, _L, _I, _P, _L, _L, _L, _I, _P],
     "yume_gemm_splitk_workspace_bytes": [_L, _L, _I],
@@ -52,10 +54,10 @@ SIGNATURES = {
     "yume_vae_unpack_output": [_P, _L, _L, _L, _L, _L, _I, _P, _P, _F, _F, _P, _P],
 }
 _RES = {"yume_last_error": c_char_p, "yume_target_arch": c_char_p, "yume_gemm_splitk_workspace_bytes": c_int64, "yume_attn_workspace_bytes": c_int64,
-        "yume_counter_workspace_bytes": c_int64}
+        "yume_counter_workspace_bytes": c_int64, "yume_gemm_workspace_bytes": c_int64}
 
 _lib = None
-ABI_VERSION = 7          # must equal YUME_ABI_VERSION in include/yume_hip.h; bumped whenever an argument list changes
+ABI_VERSION = 8          # must equal YUME_ABI_VERSION in include/yume_hip.h; bumped whenever an argument list changes
 
 
 def load():

@@ -13,10 +13,22 @@ bool w4_auto() {
 }
 }  // namespace
 
+extern "C" int64_t yume_gemm_workspace_bytes(void) { return gemm_w4::sk_workspace_bytes(gemm_w4::SK_MAX_SLOTS); }
+
 extern "C" int yume_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, int64_t M,
                               int64_t N, int64_t K, int epi, void* out, int64_t ldo, const float* gate,
                               int64_t gate_stride, const int32_t* row_idx, void* outT, int64_t ldt, int64_t n_split,
                               int variant, void* stream) {
+    return yume_gemm_bf16_ws(A, lda, W, ldw, bias, M, N, K, epi, out, ldo, gate, gate_stride, row_idx, outT, ldt, n_split, variant, nullptr, 0, stream);
+}
+
+// ... with caller-owned scratch for the stream-K tail of the one-wave-per-SIMD kernel (yume_gemm_workspace_bytes() bytes, 16-byte aligned,
+// ZERO when first handed over; a launch leaves it zero again; launches sharing one scratch must be ordered on one stream). NULL / too small:
+// the schedules without it (whole tiles, row split).
+extern "C" int yume_gemm_bf16_ws(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, int64_t M,
+                                 int64_t N, int64_t K, int epi, void* out, int64_t ldo, const float* gate,
+                                 int64_t gate_stride, const int32_t* row_idx, void* outT, int64_t ldt, int64_t n_split,
+                                 int variant, void* workspace, int64_t workspace_bytes, void* stream) {
     YUME_REQUIRE(A && W && out, "gemm_bf16: NULL pointer");
     YUME_REQUIRE(M > 0 && N > 0 && K > 0, "gemm_bf16: empty problem M=%lld N=%lld K=%lld", (long long)M, (long long)N, (long long)K);
     YUME_REQUIRE(M < (1ll << 31) && N < (1ll << 31) && K < (1ll << 31), "gemm_bf16: dimension too large");
@@ -32,7 +44,18 @@ extern "C" int yume_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t
     p.tiles_n = (int)((N + BN - 1) / BN);
     p.group_m = 8;
     p.bsW = 0; p.bsO = 0;
-    if (variant == 0 && epi != YUME_EPI_BF16_GEGLU && use_256(p, 0, epi != YUME_EPI_BF16_SPLITT || (n_split % 256) == 0)) {
+    // the stream-K tail (gemm_w4.hpp) replaces the row split where its scratch is there and the plan takes the shape
+    bool sk = false;
+    if (variant == 0 && workspace != nullptr && w4_auto() && epi != YUME_EPI_BF16_GEGLU &&
+        use_256(p, 0, epi != YUME_EPI_BF16_SPLITT || (n_split % 256) == 0) && gemm_w4::w4_applies(p, lda, epi) &&
+        (epi != YUME_EPI_BF16_SPLITT || (ldt % 8) == 0)) {
+        Problem q = p;
+        q.tiles_m = (int)((M + 255) / 256);
+        q.tiles_n = (int)((N + 255) / 256);
+        gemm_w4::w4_sk_plan(q, workspace, workspace_bytes);
+        sk = q.sk_wgs != 0;
+    }
+    if (!sk && variant == 0 && epi != YUME_EPI_BF16_GEGLU && use_256(p, 0, epi != YUME_EPI_BF16_SPLITT || (n_split % 256) == 0)) {
         // Row split (same idea as the attention's query split): when the 256x256 tiling leaves a last round that is at
         // most ~1/3 full (ffn.0 at L = 9460: 2072 tiles = 8 rounds + 24; QKV: 5 rounds + 52), run whole rounds of
         // M-tiles on the 256x256 kernel and the remaining rows (a few hundred) on the 128x128 kernel.
@@ -67,7 +90,7 @@ extern "C" int yume_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t
     // variant 3: the one-wave-per-SIMD 256x256 kernel where it applies (else as variant 2); variant 0 takes it wherever it took the 8-wave kernel
     const bool w4 = (variant == 3 || (variant == 0 && big && w4_auto())) && split_ok && gemm_w4::w4_applies(p, lda, epi) &&
                     (epi != YUME_EPI_BF16_SPLITT || (ldt % 8) == 0);
-#define YUME_GO(E) (w4 ? gemm_w4::launch_w4(E, p, al, e, st, "gemm_bf16") : big ? launch256<E>(p, al, e, st, "gemm_bf16") : launch<E>(p, al, e, st, "gemm_bf16"))
+#define YUME_GO(E) (w4 ? gemm_w4::launch_w4(E, p, al, e, st, "gemm_bf16", variant == 0 ? workspace : nullptr, workspace_bytes) : big ? launch256<E>(p, al, e, st, "gemm_bf16") : launch<E>(p, al, e, st, "gemm_bf16"))
     switch (epi) {
         case YUME_EPI_BF16: return YUME_GO(YUME_EPI_BF16);
         case YUME_EPI_BF16_GELU: return YUME_GO(YUME_EPI_BF16_GELU);

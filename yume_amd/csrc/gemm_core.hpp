@@ -55,6 +55,12 @@ struct Problem {
     int group_m;   // 256^2 kernel: M-tiles per traversal group (L2 reuse knob)
     int64_t bsW, bsO;   // batched launch (gridDim.y > 1, 128^2 kernel): W stride in elements, out stride in BYTES per batch index
     int epi_direct;     // A/B switch (env YUME_GEMM_EPI_DIRECT=1): 256^2 kernel stores bf16 tiles straight from the accumulators
+    // split-K tail of gemm_w4_kernel (gemm_w4.hpp, r6): the first sk_dp tiles of the order are whole-tile workgroups; each of the last sk_tiles
+    // tiles is cut along K into sk_s slices — slice 0 = K tiles [0, sk_lh) (its workgroup finishes the tile), slices 1 .. sk_s - 1 of sk_lt K
+    // tiles each (the last takes the rest) — run by sk_wgs more workgroups, the tail slices sk_q per workgroup. sk_ws = caller-owned scratch
+    // (one partial tile and one flag per tail slice). sk_wgs = 0: off.
+    int sk_dp, sk_tiles, sk_wgs, sk_s, sk_q, sk_lh, sk_lt;
+    char* sk_ws;
 };
 
 typedef __attribute__((address_space(3))) void lds_void;

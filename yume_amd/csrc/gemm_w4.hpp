@@ -71,6 +71,13 @@ __device__ __forceinline__ f32x4 acc_tile() {      // accumulator tile R -> VGPR
                  : "=v"(v[0]), "=v"(v[1]), "=v"(v[2]), "=v"(v[3]) : "n"(R * 4), "n"(R * 4 + 1), "n"(R * 4 + 2), "n"(R * 4 + 3) : W4_AGPRS);
     return v;
 }
+template <int R>
+__device__ __forceinline__ void acc_tile_add(f32x4 d) {      // accumulator tile R += d
+    f32x4 v = acc_tile<R>();
+    v += d;
+    asm volatile("v_accvgpr_write_b32 a[%c4], %0\n\tv_accvgpr_write_b32 a[%c5], %1\n\tv_accvgpr_write_b32 a[%c6], %2\n\tv_accvgpr_write_b32 a[%c7], %3"
+                 ::"v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "n"(R * 4), "n"(R * 4 + 1), "n"(R * 4 + 2), "n"(R * 4 + 3) : W4_AGPRS);
+}
 template <int R0, int N>
 __device__ __forceinline__ void acc_zero() {
     if constexpr (N > 0) {
@@ -496,8 +503,9 @@ __device__ __forceinline__ void w4_loop(Ctx& c, int t0, int t1, unsigned lbase) 
     }
 }
 
+// K tiles [kt0, kt0 + nk) of the tile at (m0, n0) (nk >= 3): the whole K range for a data-parallel tile, a slice for a stream-K piece
 template <bool SWAP>
-__device__ __forceinline__ void w4_mainloop(const Problem& p, const PlainA& al, char* smem, int m0, int n0) {
+__device__ __forceinline__ void w4_mainloop(const Problem& p, const PlainA& al, char* smem, int m0, int n0, int kt0, int nk) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -506,8 +514,8 @@ __device__ __forceinline__ void w4_mainloop(const Problem& p, const PlainA& al, 
     c.smem = smem;
     const unsigned lbase = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem + wave * 1024;
     c.lcur = lbase;
-    c.pa = reinterpret_cast<const char*>(al.A + (int64_t)m0 * al.lda);
-    c.pb = reinterpret_cast<const char*>(p.W + (int64_t)n0 * p.ldw);
+    c.pa = reinterpret_cast<const char*>(al.A + (int64_t)m0 * al.lda) + (int64_t)kt0 * 128;
+    c.pb = reinterpret_cast<const char*>(p.W + (int64_t)n0 * p.ldw) + (int64_t)kt0 * 128;
     const unsigned lda_b = (unsigned)al.lda * 2u, ldw_b = (unsigned)p.ldw * 2u;
     // DMA piece j of this wave: rows 32 j + 8 wave + (lane >> 3) of the tile, 16-byte chunk (lane & 7) ^ (row & 7) of the 128-byte K slice
     {
@@ -524,7 +532,6 @@ __device__ __forceinline__ void w4_mainloop(const Problem& p, const PlainA& al, 
     // fragment reads: row (lane & 15) of fragment i (rows 16 i + ...) of this wave's half, logical chunk 4 ks + (lane >> 4), swizzled
     const unsigned sw0 = (unsigned)(((lane >> 4) ^ (lane & 7)) << 4), sw1 = (unsigned)(((4 | (lane >> 4)) ^ (lane & 7)) << 4);
     const unsigned rowa = wr * 16384 + (lane & 15) * 128, rowb = OPER_BYTES + wc * 16384 + (lane & 15) * 128;
-    const int nk = p.K / BK;
     // ---- prologue: tiles 0 and 1 in flight, accumulators zeroed under their latency, F0(0) read ----
     w4_stage_all<0, 0>(c);
     c.pa += 128;
@@ -552,31 +559,168 @@ __device__ __forceinline__ void w4_mainloop(const Problem& p, const PlainA& al, 
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");      // last MFMA results -> v_accvgpr_read
 }
 
+// ---- split-K tail (r6) ----------------------------------------------------------------------------------------------------------------
+// The block's N = 3072 GEMMs are 444 tiles = 1.73 rounds of the 256 CUs, and the row split of the N = 9216 / 14336 ones leaves a remainder
+// launch: the last, partly filled round costs a whole round (profiles/r6_trace_gemm_epilogue_report.txt: o 16 %, ffn.2 14 % idle tail per CU).
+// Hybrid schedule: the first sk_dp tiles of the order (whole rounds) stay one tile per workgroup; each of the LAST R = sk_tiles tiles is cut
+// along K so that one more full round of workgroups finishes them together:
+//   * R > CUs / 2 (the N = 3072 shapes, R = 188): two slices. R "head" workgroups take K tiles [0, L_h) of one tile each; the remaining CUs
+//     take the tails [L_h, nk), q = ceil(R / (CUs - R)) of them one after the other, with L_t = nk / (q + 1): heads and tail workgroups
+//     finish together after q / (q + 1) of a tile time (R = 188: q = 3, 0.75 instead of 1);
+//   * R <= CUs / 2 (QKV: 52, ffn.0: 24): s = CUs / R equal slices of every tile, one piece per workgroup, all at once (1 / s of a tile time).
+//   (first build of the round, measured and replaced: CONTIGUOUS iteration ranges — classic stream-K, one partial per workgroup. Correct, and
+//   8 % SLOWER than whole tiles on ffn.2: neighbours sit at different K offsets, nothing is shared in the XCD's L2, and the tail streams
+//   its operands at HBM rate, 2.8 us per K tile instead of 1.4 — profiles/r6_gemm_streamk_contiguous_first_run.log. Here every workgroup of a
+//   group walks the SAME K range in step with its neighbours, as the whole-tile rounds do.)
+//   * a tail slice PUBLISHES its 256 x 256 fp32 partial (write-through `sc1` stores into the caller's scratch, every wave drains, one lane
+//     raises the slice's flag); the head FINISHES the tile: it polls the flags of the tile's tail slices, one agent-scope acquire each, adds
+//     the partials IN SLICE ORDER into its accumulators (a fixed summation order whatever the timing: results are run-to-run identical) and
+//     runs the tile's epilogue. Flags return to zero behind their reader (a launch leaves the scratch as it found it: no memset, capturable).
+// Every spin is bounded (a timeout raises the scratch's error word instead of hanging). Placement-independent: every workgroup of the tail
+// is resident (one per CU) and none waits on a workgroup that waits (MI355X_MICROARCH.md "Workgroup dispatch ..."; cdna_hip_programming.md
+// Guideline 16, recipe R1).
+constexpr int SK_SLOT_BYTES = 64 * NTHR_W4 * 16;       // one partial tile: 64 accumulator tiles x 256 lanes x 16 bytes = 256 KiB
+constexpr int SK_FLAG_STRIDE = 64;                     // one flag word per 64-byte line
+constexpr int SK_MIN_KT = 4;                           // a slice is at least this many K tiles (the loop needs three)
+constexpr int SK_MAX_SLOTS = 256;
+constexpr unsigned SK_SPIN_LIMIT = 1u << 22;           // polls of ~1 us each before a finisher gives up
+
+__host__ __device__ __forceinline__ int64_t sk_workspace_bytes(int slots) { return (int64_t)slots * (SK_SLOT_BYTES + SK_FLAG_STRIDE) + 64; }
+
+// (the slot is addressed as a wave-uniform base + a 32-bit per-lane offset that is laundered once per piece: with 64-bit per-lane pointers the
+// compiler hoisted all 64 tile addresses of a slot out of the piece loop and spilled them across the K loop)
+template <int T0, int N>
+__device__ __forceinline__ void sk_publish_tiles(const char* slot, unsigned lane_off) {
+    if constexpr (N > 0) {
+        const f32x4 v = acc_tile<T0>();
+        // write-through: the payload is visible at the agent's coherence point once this wave's vmcnt drains (Guideline 16 R1)
+        asm volatile("global_store_dwordx4 %0, %1, %2 sc1\n\ts_nop 1" ::"v"(lane_off + (unsigned)(T0 * (NTHR_W4 * 16))), "v"(v), "s"(slot) : "memory");
+        sk_publish_tiles<T0 + 1, N - 1>(slot, lane_off);
+    }
+}
+template <int T0, int N>
+__device__ __forceinline__ void sk_gather_tiles(const char* slot, unsigned lane_off) {
+    if constexpr (N > 0) {
+        f32x4 d[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) d[u] = *reinterpret_cast<const f32x4*>(slot + (lane_off + (unsigned)((T0 + u) * (NTHR_W4 * 16))));
+        static_for<0, 8>([&](auto uu) {
+            constexpr int u = decltype(uu)::value;
+            acc_tile_add<T0 + u>(d[u]);
+        });
+        sk_gather_tiles<T0 + 8, N - 8>(slot, lane_off);
+    }
+}
+
+// what follows a piece's K loop: a tail slice (slot >= 0) publishes; a head (nslice > 1) gathers the tile's tail slices; then the epilogue
+template <bool SWAP>
+__device__ __forceinline__ void w4_finish_piece(const Problem& p, const Epilogue& e, int epi, char* smem, int m0, int n0, int slot, int t, int nslice) {
+    typedef unsigned gu32;                                            // (the flag words: accessed with agent-scope atomics only)
+    char* const slots = p.sk_ws;
+    gu32* const flags = reinterpret_cast<gu32*>(p.sk_ws + (int64_t)SK_MAX_SLOTS * SK_SLOT_BYTES);
+    unsigned lane_off = threadIdx.x * 16u;
+    asm volatile("" : "+v"(lane_off));                                 // (not a loop invariant: see sk_publish_tiles)
+    if (slot >= 0) {
+        sk_publish_tiles<0, 64>(slots + (int64_t)slot * SK_SLOT_BYTES, lane_off);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // EVERY storing wave drains
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_store(flags + slot * (SK_FLAG_STRIDE / 4), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
+    if (nslice > 1) {
+        for (int j = 1; j < nslice; ++j) {                               // the tile's tail slices, in order
+            const int q = (j - 1) * p.sk_tiles + t;
+            if (threadIdx.x == 0) {
+                gu32* f = flags + q * (SK_FLAG_STRIDE / 4);
+                unsigned spins = 0;
+                while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+                    __builtin_amdgcn_s_sleep(8);
+                    if (++spins > SK_SPIN_LIMIT) {                         // never hang the device: flag the scratch, go on with what is there
+                        __hip_atomic_store(flags + SK_MAX_SLOTS * (SK_FLAG_STRIDE / 4), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        break;
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            }
+            __syncthreads();
+            sk_gather_tiles<0, 64>(slots + (int64_t)q * SK_SLOT_BYTES, lane_off);
+            __syncthreads();                                              // every wave has read the slot
+            if (threadIdx.x == 0) __hip_atomic_store(flags + q * (SK_FLAG_STRIDE / 4), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        asm volatile("s_nop 15" ::: "memory");                           // v_accvgpr_write -> v_accvgpr_read of the epilogue
+    }
+    TRACE_STAMP(1);
+    if constexpr (!SWAP) {
+        w4_epilogue<YUME_EPI_BF16_SPLITT, false>(p, e, m0, n0, smem);
+    } else {
+        switch (epi) {
+#ifndef W4_EXPERIMENT
+            case YUME_EPI_BF16_GELU: w4_epilogue<YUME_EPI_BF16_GELU, true>(p, e, m0, n0, smem); break;
+            case YUME_EPI_BF16_GELU_ERF: w4_epilogue<YUME_EPI_BF16_GELU_ERF, true>(p, e, m0, n0, smem); break;
+            case YUME_EPI_F32: w4_epilogue<YUME_EPI_F32, true>(p, e, m0, n0, smem); break;
+            case YUME_EPI_RESID: w4_epilogue<YUME_EPI_RESID, true>(p, e, m0, n0, smem); break;
+            case YUME_EPI_BF16_SPLITT: w4_epilogue<YUME_EPI_BF16_SPLITT, true>(p, e, m0, n0, smem); break;
+#endif
+            default: w4_epilogue<YUME_EPI_BF16, true>(p, e, m0, n0, smem); break;
+        }
+    }
+}
+
 // ONE kernel for every epilogue (the epilogue id is a kernel argument: the 128-MFMA loop body exists in 2 operand orders x {staging, not
-// staging} already, and instances of it that meet at a join made hipcc's register allocation spill through the accumulators)
+// staging} already, and instances of it that meet at a join made hipcc's register allocation spill through the accumulators). A
+// data-parallel workgroup is the one-piece case of the stream-K walk: the K loop exists once per operand order.
 template <int UNUSED = 0>      // (a template so that the header can be included by several translation units)
 __global__ __launch_bounds__(NTHR_W4, 1) void gemm_w4_kernel(Problem p, PlainA al, Epilogue e, int epi) {
     __shared__ __attribute__((aligned(16))) char smem[LDS_W4];
-    int start, count, m0, n0;
     TRACE_STAMP(0);
-    xcd_chunk(p.tiles_m * p.tiles_n, blockIdx.x & 7, start, count);
-    tile_origin(p, start + (blockIdx.x >> 3), m0, n0);
-    if (epi == YUME_EPI_BF16_SPLITT && n0 >= e.n_split) {
-        w4_mainloop<false>(p, al, smem, m0, n0);
-        w4_epilogue<YUME_EPI_BF16_SPLITT, false>(p, e, m0, n0, smem);
-        return;
+    const int nk = p.K / BK;
+    const int ndp = p.sk_wgs ? p.sk_dp : p.tiles_m * p.tiles_n;       // tiles walked whole, one per workgroup
+    // this workgroup's pieces: piece i = (tile t, slice j) for i in [pc0, pc1) of a list; a data-parallel workgroup has the one whole tile
+    int pc0 = 0, pc1 = 1, R = 1, tile0, head_t = 0;
+    bool tails = false;
+    if ((int)blockIdx.x < ndp) {
+        int start, count;
+        xcd_chunk(ndp, blockIdx.x & 7, start, count);
+        tile0 = start + (blockIdx.x >> 3);
+    } else {
+        const int sk = (int)blockIdx.x - ndp, per = p.sk_wgs >> 3;      // band position: XCD (sk & 7) holds positions per * xcd .. + per - 1
+        const int w = (sk & 7) * per + (sk >> 3);
+        R = p.sk_tiles;
+        tile0 = ndp;
+        if (w < R) {
+            head_t = w;                                                 // slice 0 of tile w: finishes it
+        } else {
+            tails = true;                                               // tail slices (w - R) q .. + q - 1 of the (s - 1) R, slice-major
+            const int ntail = (p.sk_s - 1) * R;
+            pc0 = (w - R) * p.sk_q;
+            pc1 = min(ntail, pc0 + p.sk_q);
+            if (pc0 >= pc1) return;                                     // (a workgroup that only rounds the launch up to whole XCD bands)
+        }
     }
-    w4_mainloop<true>(p, al, smem, m0, n0);
-    TRACE_STAMP(1);
-    switch (epi) {
-#ifndef W4_EXPERIMENT
-        case YUME_EPI_BF16_GELU: w4_epilogue<YUME_EPI_BF16_GELU, true>(p, e, m0, n0, smem); break;
-        case YUME_EPI_BF16_GELU_ERF: w4_epilogue<YUME_EPI_BF16_GELU_ERF, true>(p, e, m0, n0, smem); break;
-        case YUME_EPI_F32: w4_epilogue<YUME_EPI_F32, true>(p, e, m0, n0, smem); break;
-        case YUME_EPI_RESID: w4_epilogue<YUME_EPI_RESID, true>(p, e, m0, n0, smem); break;
-        case YUME_EPI_BF16_SPLITT: w4_epilogue<YUME_EPI_BF16_SPLITT, true>(p, e, m0, n0, smem); break;
-#endif
-        default: w4_epilogue<YUME_EPI_BF16, true>(p, e, m0, n0, smem); break;
+    for (int pc = pc0; pc < pc1; ++pc) {
+        int t = head_t, j = 0, k0 = 0, k1 = nk, slot = -1, nslice = 1;
+        if (p.sk_wgs && (int)blockIdx.x >= ndp) {
+            if (tails) {
+                j = 1 + pc / R;
+                t = pc - (j - 1) * R;
+                k0 = p.sk_lh + (j - 1) * p.sk_lt;
+                k1 = j == p.sk_s - 1 ? nk : k0 + p.sk_lt;
+                slot = pc;
+            } else {
+                k1 = p.sk_lh;
+                nslice = p.sk_s;
+            }
+        }
+        int m0, n0;
+        tile_origin(p, tile0 + t, m0, n0);
+        if (epi == YUME_EPI_BF16_SPLITT && n0 >= e.n_split) {
+            w4_mainloop<false>(p, al, smem, m0, n0, k0, k1 - k0);
+            w4_finish_piece<false>(p, e, epi, smem, m0, n0, slot, t, nslice);
+        } else {
+            w4_mainloop<true>(p, al, smem, m0, n0, k0, k1 - k0);
+            w4_finish_piece<true>(p, e, epi, smem, m0, n0, slot, t, nslice);
+        }
+        if (pc + 1 < pc1) __syncthreads();                              // (LDS is free before the next piece's first DMA lands)
     }
     TRACE_STAMP(2);
 }
@@ -592,13 +736,59 @@ inline bool w4_applies(const Problem& p, int64_t lda, int epi) {
            epi == YUME_EPI_BF16_SPLITT;
 }
 
-inline int launch_w4(int epi, const Problem& p128, const PlainA& al, const Epilogue& e, hipStream_t st, const char* what) {
+// split-K plan of a launch's tail (host), or sk_wgs = 0
+inline void w4_sk_plan(Problem& p, void* ws, int64_t ws_bytes) {
+    p.sk_dp = 0; p.sk_tiles = 0; p.sk_wgs = 0; p.sk_s = 1; p.sk_q = 1; p.sk_lh = 0; p.sk_lt = 0; p.sk_ws = nullptr;
+    static const bool on = [] { const char* v = getenv("YUME_GEMM_SK"); return !v || atoi(v) != 0; }();
+    static const int ncu = [] {
+        int d = 0, n = 0;
+        if (hipGetDevice(&d) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, d) != hipSuccess) n = 0;
+        return n;
+    }();
+    if (!on || ws == nullptr || ncu < 64 || ncu > SK_MAX_SLOTS || (ncu & 7) != 0) return;
+    if (ws_bytes < sk_workspace_bytes(SK_MAX_SLOTS) || ((uintptr_t)ws & 15) != 0) return;
+    const int T = p.tiles_m * p.tiles_n, nk = p.K / BK;
+    const int R = T % ncu;
+    if (R == 0 || T < ncu) return;                                     // whole rounds already, or a launch that does not fill the chip
+    // Where it pays (profiles/r6_gemm_splitk_tail_ab.log, 5B shapes, back-to-back launches): ffn.2 (K = 14336, R = 188) 0.729 -> 0.701 ms; the
+    // K = 3072 shapes LOSE — o 0.182 -> 0.202, cross-q 0.152 -> 0.172 (a tail slice of 12 K tiles pays a K-loop prologue and a 256 KiB
+    // publish, the head a 256 KiB gather: more than the quarter tile they save), QKV 0.466 -> 0.474 and ffn.0 0.708 -> 0.730 (4 / 10 slices
+    // of 12 / 4 K tiles). So: long K only, and only the two-slice form. YUME_GEMM_SK_MIN_NK overrides the threshold (A/B runs).
+    static const int min_nk = [] { const char* v = getenv("YUME_GEMM_SK_MIN_NK"); return v ? atoi(v) : 96; }();
+    if (nk < min_nk) return;
+    int s, q, lh, lt;
+    if (2 * R > ncu) {                                                 // heads + tails, q tails per tail workgroup
+        s = 2;
+        q = (R + (ncu - R) - 1) / (ncu - R);
+        lt = nk / (q + 1);
+        lh = nk - lt;
+    } else {                                                           // s equal slices, every piece its own workgroup
+        s = ncu / R;
+        if (s > nk / SK_MIN_KT) s = nk / SK_MIN_KT;
+        q = 1;
+        lt = nk / s;
+        lh = lt;
+    }
+    if (s < 2 || lt < SK_MIN_KT || lh < SK_MIN_KT || (s - 1) * R > SK_MAX_SLOTS) return;
+    const int nwg = R + ((s - 1) * R + q - 1) / q;
+    if (nwg > ncu) return;
+    p.sk_tiles = R;
+    p.sk_dp = T - R;
+    p.sk_s = s; p.sk_q = q; p.sk_lh = lh; p.sk_lt = lt;
+    p.sk_wgs = (nwg + 7) / 8 * 8;                                      // whole XCD bands (the surplus workgroups return at once)
+    p.sk_ws = (char*)ws;
+}
+
+inline int launch_w4(int epi, const Problem& p128, const PlainA& al, const Epilogue& e, hipStream_t st, const char* what, void* ws = nullptr,
+                     int64_t ws_bytes = 0) {
     Problem p = p128;
     p.tiles_m = (p.M + 255) / 256;
     p.tiles_n = (p.N + 255) / 256;
     p.group_m = g_group_m;
     { static const int d = [] { const char* v = getenv("YUME_GEMM_EPI_DIRECT"); return v ? atoi(v) : 0; }(); p.epi_direct = d; }
-    hipLaunchKernelGGL(gemm_w4_kernel<0>, dim3((unsigned)(p.tiles_m * p.tiles_n)), dim3(NTHR_W4), 0, st, p, al, e, epi);
+    w4_sk_plan(p, ws, ws_bytes);
+    const unsigned grid = p.sk_wgs ? (unsigned)(p.sk_dp + p.sk_wgs) : (unsigned)(p.tiles_m * p.tiles_n);
+    hipLaunchKernelGGL(gemm_w4_kernel<0>, dim3(grid), dim3(NTHR_W4), 0, st, p, al, e, epi);
     YUME_CHECK_LAUNCH(what);
     return YUME_OK;
 }

@@ -83,6 +83,28 @@ def adaln_modulate(x, mul, add, tab_stride, row_idx, add_one, out, out_kind=0, e
     return out
 
 
+# scratch of the GEMM's stream-K tail (yume_gemm_bf16_ws): one zero-initialised buffer per (device, stream) — launches sharing it are ordered
+_gemm_ws = {}
+
+
+def _gemm_workspace(t):
+    key = _ws_key(t)
+    ws = _gemm_ws.get(key)
+    if ws is None:
+        n = int(_lib.load().yume_gemm_workspace_bytes())
+        ws = _gemm_ws[key] = torch.zeros(n, dtype=torch.uint8, device=t.device)
+    return ws
+
+
+def gemm_stream_k_error(device=None):
+    """True if a stream-K finisher of any GEMM on `device` timed out waiting for a partial tile (the error word of the scratch)."""
+    bad = False
+    for (idx, _), ws in _gemm_ws.items():
+        if device is None or torch.device(device).index in (None, idx):
+            bad = bad or bool(ws[-64:].any().item())
+    return bad
+
+
 def gemm_bf16(a, w, bias, out, epi=EPI_BF16, gate=None, gate_stride=0, row_idx=None, out_t=None, n_split=0,
               variant=0):
     """acc = a @ w.T (a bf16 [M,K], w bf16 [N,K]); epilogue selected by `epi` (see yume_hip.h)."""
@@ -99,8 +121,12 @@ def gemm_bf16(a, w, bias, out, epi=EPI_BF16, gate=None, gate_stride=0, row_idx=N
     tp, ldt = (None, 0)
     if out_t is not None:
         tp, ldt = _rows(out_t, "out_t")
-    rc = lib.yume_gemm_bf16(ap, lda, wp, ldw, _ptr(bias), M, N, K, epi, op, ldo, _ptr(gate), gate_stride,
-                            _ptr(row_idx), tp, ldt, n_split, variant, _stream())
+    # the scratch is handed over where the stream-K plan can take the shape at all (big launches of the automatic variant)
+    ws = _gemm_workspace(a) if (variant == 0 and M * N >= 256 * 256 * 256 and not torch.cuda.is_current_stream_capturing()) else None
+    if ws is None and variant == 0 and M * N >= 256 * 256 * 256:
+        ws = _gemm_ws.get(_ws_key(a))                     # under capture: only a scratch that exists already (allocated outside)
+    rc = lib.yume_gemm_bf16_ws(ap, lda, wp, ldw, _ptr(bias), M, N, K, epi, op, ldo, _ptr(gate), gate_stride,
+                               _ptr(row_idx), tp, ldt, n_split, variant, _ptr(ws), ws.numel() if ws is not None else 0, _stream())
     _lib.check(rc, "yume_gemm_bf16")
     return out
 
