@@ -266,9 +266,12 @@ def kernel_rooflines(prof, steps, ms_per_step, L, cfg, Lc=512):
         "gemm_cross_q": ("mfma", 2.0 * L * C * C, f"cross q GEMM {L}x{C}x{C}"),
         "gemm_cross_o": ("mfma", 2.0 * L * C * C, f"cross o-proj GEMM {L}x{C}x{C}, residual epilogue"),
         "gemm_ffn0": ("mfma", 2.0 * L * Fd * C, f"ffn.0 GEMM {L}x{Fd}x{C} + bias + GELU (gemm_w4_kernel + gemm128_kernel on the row remainder)"),
-        "gemm_ffn2": ("mfma", 2.0 * L * C * Fd, f"ffn.2 GEMM {L}x{C}x{Fd}, gate*y + residual epilogue"),
+        "gemm_ffn2": ("mfma", 2.0 * L * C * Fd, f"ffn.2 GEMM {L}x{C}x{Fd}, gate*y + residual epilogue (gemm_w4_kernel with the split-K tail: 256 whole tiles + 188 tiles as heads / tails)"),
         "adaln": ("hbm", 6.0 * L * C, "LayerNorm + modulate: 4*L*C read + 2*L*C written"),
-        "rmsnorm_rope": ("hbm", None, "RMSNorm (+RoPE) in place on q|k / cross q (2 B read + 2 B written per element)"),
+        # two launches per block share the group: q|k with RoPE (2C columns read + written in place, + the 512-byte fp32 cos / sin row of
+        # the token) and the cross-attention q (C columns): the figure is their mean, as the launch time is
+        "rmsnorm_rope": ("hbm", (4.0 * 2 * C * L + 512.0 * L + 4.0 * C * L) / 2, "RMSNorm (+RoPE) in place on q|k / cross q (2 B read + 2 B written per "
+                         "element, + the token's RoPE row on q|k): mean of the block's two launches"),
     }
     out = []
     for name, evs in prof.items():

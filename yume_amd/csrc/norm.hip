@@ -112,6 +112,102 @@ __global__ __launch_bounds__(NT) void adaln_kernel(const float* __restrict__ x, 
     }
 }
 
+// (r6) TWO rows per workgroup for the block's own shape class (C <= 3072, bf16 out): the loads of both rows and of their modulation rows are
+// in flight before the first reduction, and one pair of barriers serves both rows' statistics — per row the same arithmetic in the same order
+// as adaln_kernel<3> (bit-identical results). Measured in the step: adaLN 33.6 -> see profiles/r6_glue_two_rows_ab.log.
+__device__ __forceinline__ void block_sum2(float& a, float& b, float* red /*[16]*/) {
+    a = wave_sum(a);
+    b = wave_sum(b);
+    const int wid = threadIdx.x >> 6;
+    __syncthreads();  // protect `red` against the previous use
+    if ((threadIdx.x & 63) == 0) { red[wid] = a; red[8 + wid] = b; }
+    __syncthreads();
+    float ta = 0.f, tb = 0.f;
+#pragma unroll
+    for (int i = 0; i < NT / 64; ++i) { ta += red[i]; tb += red[8 + i]; }
+    a = ta;
+    b = tb;
+}
+
+__global__ __launch_bounds__(NT) void adaln2_kernel(const float* __restrict__ x, int64_t ldx, int T, int C, float eps,
+                                                    const float* __restrict__ mul, const float* __restrict__ add,
+                                                    int64_t tab_stride, const int32_t* __restrict__ row_idx,
+                                                    float add_one, unsigned short* __restrict__ out, int64_t ldo) {
+    constexpr int MAXV = 3;
+    __shared__ float red[16];
+    const int64_t t0 = 2 * (int64_t)blockIdx.x;
+    const bool two = t0 + 1 < T;                                   // (uniform) the last block of an odd T holds one row
+    const int64_t tr[2] = {t0, two ? t0 + 1 : t0};
+    const int nvec = C >> 2;
+    f32x4 v[2][MAXV], m4v[2][MAXV], a4v[2][MAXV];
+    float s[2] = {0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int vi = threadIdx.x + i * NT;
+            if (vi < nvec) {
+                v[r][i] = *reinterpret_cast<const f32x4*>(x + tr[r] * ldx + 4 * vi);
+            } else {
+                v[r][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int64_t row = row_idx ? (int64_t)row_idx[tr[r]] : 0;
+        const float* mr = mul + row * tab_stride;
+        const float* ar = add + row * tab_stride;
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int vi = threadIdx.x + i * NT;
+            if (vi < nvec) {
+                m4v[r][i] = *reinterpret_cast<const f32x4*>(mr + 4 * vi);
+                a4v[r][i] = *reinterpret_cast<const f32x4*>(ar + 4 * vi);
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) s[r] += (v[r][i][0] + v[r][i][1]) + (v[r][i][2] + v[r][i][3]);
+    block_sum2(s[0], s[1], red);
+    const float mean[2] = {s[0] / (float)C, s[1] / (float)C};
+    float q[2] = {0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int vi = threadIdx.x + i * NT;
+            if (vi < nvec) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float d = v[r][i][j] - mean[r];
+                    q[r] += d * d;
+                }
+            }
+        }
+    block_sum2(q[0], q[1], red);
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        if (r == 1 && !two) break;
+        const float rstd = rsqrtf(q[r] / (float)C + eps);
+        unsigned short* ob = out + tr[r] * ldo;
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int vi = threadIdx.x + i * NT;
+            if (vi < nvec) {
+                f32x4 y;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) y[j] = (v[r][i][j] - mean[r]) * rstd * (m4v[r][i][j] + add_one) + a4v[r][i][j];
+                u32x2 hi;
+                hi[0] = pack_bf16x2(y[0], y[1]);
+                hi[1] = pack_bf16x2(y[2], y[3]);
+                *reinterpret_cast<u32x2*>(ob + 4 * vi) = hi;
+            }
+        }
+    }
+}
+
 // RMSNorm(+RoPE) in place. Each thread owns NV 16-byte vectors (8 bf16) of the row:
 // vector index vi = tid + i*NT, i < NV; part(vi) = vi / (C/8) is wave-uniform since (C/8)%64==0.
 template <int NV>
@@ -183,6 +279,100 @@ __global__ __launch_bounds__(NT) void rmsnorm_rope_kernel(unsigned short* __rest
     }
 }
 
+// two rows per workgroup (r6; see adaln2_kernel): per row the arithmetic of rmsnorm_rope_kernel in the same order
+template <int NV>
+__global__ __launch_bounds__(NT) void rmsnorm_rope2_kernel(unsigned short* __restrict__ buf, int64_t ld, int T, int C, int nparts,
+                                                           const float* __restrict__ w, float eps, const float* __restrict__ rope) {
+    __shared__ float red[32];
+    const int64_t t0 = 2 * (int64_t)blockIdx.x;
+    const bool two = t0 + 1 < T;
+    const int64_t tr[2] = {t0, two ? t0 + 1 : t0};
+    const int vpp = C >> 3;
+    const int nvec = vpp * nparts;
+    u16x8 v[2][NV];
+    float ss[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int vi = threadIdx.x + i * NT;
+            if (vi < nvec) v[r][i] = *reinterpret_cast<const u16x8*>(buf + tr[r] * ld + 8 * vi);
+        }
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int vi = threadIdx.x + i * NT;
+            if (vi < nvec) {
+                float a = 0.f;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float f = bf16_to_f32(v[r][i][j]);
+                    a += f * f;
+                }
+                if (vi < vpp) ss[r][0] += a; else ss[r][1] += a;
+            }
+        }
+    {   // the four sums in one pair of barriers (each: wave sum, then the waves' partials in wave order, as block_sum)
+        float p[4] = {wave_sum(ss[0][0]), wave_sum(ss[0][1]), wave_sum(ss[1][0]), wave_sum(ss[1][1])};
+        const int wid = threadIdx.x >> 6;
+        if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) red[8 * k + wid] = p[k];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float tt = 0.f;
+#pragma unroll
+            for (int i = 0; i < NT / 64; ++i) tt += red[8 * k + i];
+            p[k] = tt;
+        }
+        ss[0][0] = p[0]; ss[0][1] = p[1]; ss[1][0] = p[2]; ss[1][1] = p[3];
+    }
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        if (r == 1 && !two) break;
+        const float r0 = rsqrtf(ss[r][0] / (float)C + eps);
+        const float r1 = rsqrtf((nparts > 1 ? ss[r][1] : 0.f) / (float)C + eps);
+        const float* rp = rope ? rope + tr[r] * 128 : nullptr;
+        unsigned short* row = buf + tr[r] * ld;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int vi = threadIdx.x + i * NT;
+            if (vi < nvec) {
+                const float rr = vi >= vpp ? r1 : r0;
+                const int c0 = 8 * vi;
+                const f32x4 w0 = *reinterpret_cast<const f32x4*>(w + c0);
+                const f32x4 w1 = *reinterpret_cast<const f32x4*>(w + c0 + 4);
+                float y[8];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    y[j] = bf16_to_f32(v[r][i][j]) * rr * w0[j];
+                    y[4 + j] = bf16_to_f32(v[r][i][4 + j]) * rr * w1[j];
+                }
+                if (rp) {
+                    const int pr = (c0 & 127) >> 1;
+                    const f32x4 cs0 = *reinterpret_cast<const f32x4*>(rp + 2 * pr);
+                    const f32x4 cs1 = *reinterpret_cast<const f32x4*>(rp + 2 * pr + 4);
+                    const float cs[8] = {cs0[0], cs0[1], cs0[2], cs0[3], cs1[0], cs1[1], cs1[2], cs1[3]};
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float a = y[2 * q], b = y[2 * q + 1];
+                        const float c = cs[2 * q], sn = cs[2 * q + 1];
+                        y[2 * q] = a * c - b * sn;
+                        y[2 * q + 1] = a * sn + b * c;
+                    }
+                }
+                u32x4 o;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] = pack_bf16x2(y[2 * j], y[2 * j + 1]);
+                *reinterpret_cast<u32x4*>(row + 8 * vi) = o;
+            }
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int yume_adaln_modulate(const float* x, int64_t ldx, int64_t T, int64_t C, float eps, const float* mul,
@@ -196,7 +386,11 @@ extern "C" int yume_adaln_modulate(const float* x, int64_t ldx, int64_t T, int64
     hipStream_t st = (hipStream_t)stream;
     const float one = add_one ? 1.f : 0.f;
     dim3 grid((unsigned)T), block(NT);
-    if (C <= NT * 4 * 3)
+    static const bool two_rows = [] { const char* v = getenv("YUME_NORM_TWO_ROWS"); return !v || atoi(v) != 0; }();
+    if (two_rows && C <= NT * 4 * 3 && out_kind == 0 && T >= 1024 && T < (1ll << 31))
+        hipLaunchKernelGGL(adaln2_kernel, dim3((unsigned)((T + 1) / 2)), block, 0, st, x, ldx, (int)T, (int)C, eps, mul, add, tab_stride, row_idx, one,
+                           (unsigned short*)out, ldo);
+    else if (C <= NT * 4 * 3)
         hipLaunchKernelGGL(adaln_kernel<3>, grid, block, 0, st, x, ldx, (int)C, eps, mul, add, tab_stride, row_idx, one, out, ldo, out_kind);
     else if (C <= NT * 4 * 5)
         hipLaunchKernelGGL(adaln_kernel<5>, grid, block, 0, st, x, ldx, (int)C, eps, mul, add, tab_stride, row_idx, one, out, ldo, out_kind);
@@ -252,6 +446,14 @@ static int rmsnorm_rope_impl(void* buf, int64_t ld, int64_t T, int64_t C, int np
     unsigned short* b = reinterpret_cast<unsigned short*>(buf);
     const int64_t nvec = (C / 8) * nparts;
     dim3 grid((unsigned)T), block(NT);
+    static const bool two_rows = [] { const char* v = getenv("YUME_NORM_TWO_ROWS"); return !v || atoi(v) != 0; }();
+    if (two_rows && wperiod == 1 && nvec <= NT * 3 && T >= 1024 && T < (1ll << 31)) {
+        const dim3 g2((unsigned)((T + 1) / 2));
+        if (nvec <= NT * 2) hipLaunchKernelGGL(rmsnorm_rope2_kernel<2>, g2, block, 0, st, b, ld, (int)T, (int)C, nparts, w, eps, rope);
+        else hipLaunchKernelGGL(rmsnorm_rope2_kernel<3>, g2, block, 0, st, b, ld, (int)T, (int)C, nparts, w, eps, rope);
+        YUME_CHECK_LAUNCH("rmsnorm_rope");
+        return YUME_OK;
+    }
     if (nvec <= NT * 2)
         hipLaunchKernelGGL(rmsnorm_rope_kernel<2>, grid, block, 0, st, b, ld, (int)C, nparts, w, eps, rope, wperiod);
     else if (nvec <= NT * 3)
