@@ -466,3 +466,24 @@ def test_conv_halo_n_folded_upsample_192_to_96_vs_torch(H, W):
     for sl in ((slice(None), slice(None), 0), (slice(None), slice(None), -1), (slice(None), slice(None), slice(None), 0),
                (slice(None), slice(None), slice(None), -1), (slice(None), slice(None), 1), (slice(None), slice(None), slice(None), 1)):
         assert rel_l2(got[sl], want[sl]) < 5e-3, sl
+
+
+@pytest.mark.parametrize("Cin,Cout,H,W", [(96, 192, 130, 134), (160, 320, 128, 136)])
+def test_conv_halo_n_widening_convolutions_vs_torch(Cin, Cout, H, W):
+    """the first convolution of a level that doubles the channels (96 -> 192 in the Wan2.1 encoder, 160 -> 320 in the Wan2.2 encoder): one
+    conv_halo_n launch per 96 / 160 output channels, plain and fused-shortcut epilogue."""
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    T = 2
+    x = rnd(Cin, T, H, W, seed=71).bfloat16().float()
+    cache = rnd(Cin, 2, H, W, seed=72).bfloat16().float()
+    w = (rnd(Cout, Cin, 3, 3, 3, seed=73) * (27 * Cin) ** -0.5).bfloat16().float()
+    b = rnd(Cout, seed=74) * 0.1
+    want = F.conv3d(F.pad(torch.cat([cache, x], dim=1).unsqueeze(0), (1, 1, 1, 1)), w, b)[0]
+    out = torch.empty(T, H, W, Cout, dtype=torch.bfloat16, device=DEV)
+    V.conv3d_cl(cl(x), cl(cache), pack_w(w), b.to(DEV), Cout, (3, 3, 3), (1, 1, 1), (2, 1, 1), False, out, V.EPI_BF16, zero_page=zero_page())
+    got = ncthw(out)
+    assert rel_l2(got, want) < 5e-3
+    assert rel_l2(got[:Cout // 2], want[:Cout // 2]) < 5e-3 and rel_l2(got[Cout // 2:], want[Cout // 2:]) < 5e-3
+    skip = rnd(Cout, T, H, W, seed=75).bfloat16().float()
+    V.conv3d_cl(cl(x), cl(cache), pack_w(w), b.to(DEV), Cout, (3, 3, 3), (1, 1, 1), (2, 1, 1), False, out, V.EPI_ADD, add=cl(skip), zero_page=zero_page())
+    assert rel_l2(ncthw(out), want + skip) < 5e-3

@@ -269,15 +269,29 @@ extern "C" int yume_conv3d_cl(const void* x, const void* cache, int64_t ldc, int
         // 96 channels: two waves per SIMD (8 waves x 4 m-tiles of one workgroup; measured 3-5 % ahead of 4 waves x 8 m-tiles in the first build,
         // whose unrolled tap loop no longer fits the register file without scratch traffic: not instantiated); 160 channels / the 16-channel head:
         // one wave per SIMD (profiles/r6_conv_halo_n_ablations.log)
-        int rc;
-        if (ups)
-            rc = addep ? -2 : conv_halo_n::launch_inst<6, 4, 8, 64, 8, true>(hp, To, Ho, Wo, false, s);
-        else if (conv_halo_n::instance(Cin, Cout) == 16)
-            rc = conv_halo_n::launch_inst<1, 8, 8, 64, 4>(hp, To, Ho, Wo, addep, s);
-        else if (conv_halo_n::instance(Cin, Cout) == 96)
-            rc = conv_halo_n::launch_inst<6, 4, 8, 64, 8>(hp, To, Ho, Wo, addep, s);
-        else
-            rc = conv_halo_n::launch_inst<10, 4, 4, 64, 4>(hp, To, Ho, Wo, addep, s);
+        int rc = 0;
+        const int inst = conv_halo_n::instance(Cin, Cout, ups);
+        // an N tile is the instance's 96 / 160 channels: a convolution that widens the level (96 -> 192, 160 -> 320) is one launch per tile of
+        // output channels (the input is read once per launch: two launches at 1.1 PF beat one on the generic-loader kernel at 0.44)
+        const int nchunk = (inst == 96 || inst == 160) ? (int)(Cout / inst) : 1;
+        for (int ch = 0; ch < nchunk && rc == 0; ++ch) {
+            conv_halo_n::Params q = hp;
+            if (nchunk > 1) {
+                q.w = hp.w + (int64_t)ch * inst * ldw;
+                q.bias = bias ? bias + ch * inst : nullptr;
+                q.out = hp.out + ch * inst;
+                q.add = hp.add ? hp.add + ch * inst : nullptr;
+                q.cout = inst;
+            }
+            if (ups)
+                rc = addep ? -2 : conv_halo_n::launch_inst<6, 4, 8, 64, 8, true>(q, To, Ho, Wo, false, s);
+            else if (inst == 16)
+                rc = conv_halo_n::launch_inst<1, 8, 8, 64, 4>(q, To, Ho, Wo, addep, s);
+            else if (inst == 96)
+                rc = conv_halo_n::launch_inst<6, 4, 8, 64, 8>(q, To, Ho, Wo, addep, s);
+            else
+                rc = conv_halo_n::launch_inst<10, 4, 4, 64, 4>(q, To, Ho, Wo, addep, s);
+        }
         YUME_REQUIRE(rc == 0, "conv3d_cl: too many tiles (or an upsample convolution with a shortcut)");
         YUME_CHECK_LAUNCH("conv3d_cl");
         return YUME_OK;

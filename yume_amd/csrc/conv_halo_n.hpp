@@ -288,8 +288,8 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv_halo_n_kernel(Params p) 
 inline int instance(int64_t Cin, int64_t Cout, int ups = 0) {
     if (ups) return (Cin % 32 == 0 && Cout == 96) ? 96 : 0;  // the 192 -> 96 upsample convolution of the Wan2.1 decoder (37 % of a 256-wide N tile)
     if (Cin % 32 != 0 || Cin % 64 == 0) return 0;            // whole 64-wide K tiles are conv_w4's / the fast loader's
-    if (Cout == 96) return 96;
-    if (Cout == 160) return 160;
+    if (Cout == 96 || Cout == 192) return 96;                // (192 = two launches over 96 output channels each: the level's widening convolution)
+    if (Cout == 160 || Cout == 320) return 160;              // (320 = two launches of 160)
     if (Cout <= 16) return 16;                               // the Wan2.1 decoder's head, 96 -> 3 (+1) channels at full resolution (conv_halo.hpp's case at Cin % 64 != 0)
     return 0;
 }
