@@ -172,8 +172,10 @@ int yume_rmsnorm_rows_periodic(void* buf, int64_t ld, int64_t T, int64_t C, cons
  *    wan/modules/model.py:379-387) using the fp32 accumulator before rounding.
  * variant: 0 = automatic (Lk >= 1536 and Lq >= 256: the one-wave-per-SIMD kernel, 256 queries per workgroup; otherwise
  *    the 4-wave LDS-DMA kernel), 1 = 4-wave register-staged kernel, 2 = 4-wave LDS-DMA kernel, 4 = 8-wave ping-pong
- *    kernel, 7 = one-wave-per-SIMD kernel (attn_fwd7.hip), 8 = its persistent form (attn_fwd8.hip; needs the two flags below). All
- *    compute the same function (tests compare them).
+ *    kernel, 7 = one-wave-per-SIMD kernel (attn_fwd7.hip), 8 = its persistent form (attn_fwd8.hip; needs the two flags below),
+ *    9 = the short-key kernel with K and V^T resident in registers (attn_cross_rk.hpp, r6: 448 < Lk <= 512, Lq >= 1024, ldvt >= 512, and
+ *    for Lk < 512 YUME_ATTN_KV_PADDED — the 512-token text cross-attention; measured slower than the 4-wave kernel as built, so variant 0
+ *    takes it only with env YUME_ATTN_RK=1). All compute the same function (tests compare them).
  *    | YUME_ATTN_Q_PRESCALED: Q already carries scale * log2(e) — the caller folded that factor into the producer of Q before
  *    its one bf16 rounding (the DiT engine multiplies it into the RMSNorm weight of q, so yume_rmsnorm_rope writes it) — and
  *    `scale` is ignored:  O = sum_j 2^<Q,K_j> V_j / sum_j 2^<Q,K_j>.  The scores then leave the matrix pipe as the exponents
@@ -188,7 +190,7 @@ int yume_rmsnorm_rows_periodic(void* buf, int64_t ld, int64_t T, int64_t C, cons
  *    kernel (attn_fwd8.hip: one resident workgroup per CU draws (head, query block) items by ticket and streams K / V^T tiles
  *    continuously across them — the ragged last key tile is fetched like any other and only masked). Which calls take it:
  *      variant 0 (automatic): both flags AND Lk >= 1536 AND Lq >= 256 (where variant 0 would take the one-wave-per-SIMD kernel at all;
- *        the 512-key cross-attention stays on the 4-wave kernel, which measured faster there) AND a registered counter workspace
+ *        the 512-key cross-attention stays on the 4-wave kernel, which measured faster there — also than r6's variant 9) AND a registered counter workspace
  *        (yume_counter_workspace_init) AND Lq * ldq * 2 + 512 < 2^32 (the kernel addresses a query row by a 32-bit byte offset from
  *        its head's base). A call that misses one of these runs variant 7 / 2 as before — silently, it is the same function;
  *        env YUME_ATTN_V8=0 keeps variant 0 off the persistent kernel (A/B runs);

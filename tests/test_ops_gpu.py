@@ -222,6 +222,49 @@ def test_attention_accumulate_and_transposed_operand(variant):
     assert (got.double() - want).abs().max() <= 2e-2 * want.abs().max()
 
 
+@pytest.mark.parametrize("Lq,Lk,H", [(1024, 512, 2), (2100, 512, 4), (1030, 512, 24), (1500, 500, 3), (3000, 449, 2)])
+@pytest.mark.parametrize("variant", [9])
+def test_cross_attention_with_resident_k_and_v(Lq, Lk, H, variant):
+    """attn_cross_rk_kernel (r6): the 512-key cross-attention with the head's K / V^T in registers, persistent workgroups, P^T exchanged through
+    LDS in fragment order. Exact softmax against fp64; scaled and prescaled q; ragged Lq; ragged Lk in (448, 512) with the padded operands
+    the engine hands over (YUME_ATTN_KV_PADDED: K readable and V^T finite up to 512); accumulate; a V that exposes any key / head permutation."""
+    q, k, v = (rnd(L, H, 128, seed=s, dtype=torch.bfloat16) for L, s in ((Lq, 1), (Lk, 2), (Lk, 3)))
+
+    def run(qq, vv, scale=None, prescaled=False, acc=None):
+        kp = torch.zeros(512, H * 128, dtype=torch.bfloat16, device=DEV)
+        kp[:Lk] = k.reshape(Lk, H * 128).to(DEV)
+        vt = torch.zeros(H * 128, 512, dtype=torch.bfloat16, device=DEV)
+        ops.transpose_bf16(vv.reshape(Lk, H * 128).to(DEV), vt)
+        out = torch.empty(Lq, H * 128, dtype=torch.bfloat16, device=DEV) if acc is None else acc
+        ops.attn_fwd(qq.reshape(Lq, H * 128).to(DEV), kp[:Lk], vt, out, Lq, Lk, H, scale=scale, accumulate=acc is not None, variant=variant,
+                     q_prescaled=prescaled, kv_padded=True)
+        return out.cpu().view(Lq, H, 128)
+    want = attn_ref(q, k, v, 1 / math.sqrt(128))
+    got = run(q, v)
+    assert torch.isfinite(got).all()
+    assert (got.double() - want).abs().max() <= 1.5e-2 * max(want.abs().max().item(), 1e-3)
+    assert rel_l2(got, want) < 6e-3
+    assert torch.equal(run(q, v), got)                                   # run-to-run identical
+    qp = _prescale(q)
+    gp = run(qp, v, prescaled=True)
+    assert rel_l2(gp, attn_ref(qp, k, v, math.log(2.0))) < 6e-3
+    g3 = run(q, v, scale=0.3)
+    assert (g3.double() - attn_ref(q, k, v, 0.3)).abs().max() <= 2e-2 * attn_ref(q, k, v, 0.3).abs().max()
+    base = rnd(Lq, H * 128, seed=10, dtype=torch.bfloat16)
+    ga = run(q, v, acc=base.to(DEV).clone())
+    assert (ga.double() - (want + base.view(Lq, H, 128).double())).abs().max() <= 2e-2 * (want + base.view(Lq, H, 128).double()).abs().max()
+    v2 = torch.zeros(Lk, H, 128)
+    v2[:, :, 0] = torch.arange(Lk).view(Lk, 1) / 64.0
+    v2[:, :, 1] = torch.arange(H).view(1, H) + 1.0
+    v2[:, :, 2:] = (torch.arange(126).view(1, 1, 126) % 7) * 0.25
+    v2 = v2.to(torch.bfloat16)
+    w2 = attn_ref(q, k, v2, 1 / math.sqrt(128))
+    assert (run(q, v2).double() - w2).abs().max() <= 2e-2 * w2.abs().max()
+    if variant == 9:                                                      # the same function as the streaming kernel computes
+        ref2 = run_attn(q, k, v, variant=2)
+        assert rel_l2(got, ref2) < 6e-3
+
+
 def _prescale(q, scale=1 / math.sqrt(128)):
     """what the DiT engine hands the attention kernel: q * scale * log2(e), rounded to bf16 ONCE (there: inside yume_rmsnorm_rope)"""
     return (q.double() * (scale * math.log2(math.e))).to(torch.bfloat16)

@@ -24,6 +24,7 @@
 #include "attn_args.hpp"
 #include "counters.hpp"
 #include "trace.hpp"
+#include "attn_cross_rk.hpp"
 
 namespace {
 
@@ -1205,6 +1206,13 @@ extern "C" int yume_attn_fwd_ws(const void* Q, int64_t ldq, const void* K, int64
             YUME_CHECK_LAUNCH("attn_fwd");
             return YUME_OK;
         }
+    }
+    if (variant == 9) YUME_REQUIRE(attn_rk::fits(Lq, Lk, ldvt, kv_pad), "attn_fwd: variant 9 needs 448 < Lk <= 512 (padded), Lq >= 1024, ldvt >= 512");
+    if (variant == 9 || (variant == 0 && attn_rk::applies(Lq, Lk, ldvt, kv_pad))) {
+        // the 512-key cross-attention: K and V^T resident in registers, persistent workgroups (attn_cross_rk.hpp, r6)
+        attn_rk::launch(a, cu_count(), st);
+        YUME_CHECK_LAUNCH("attn_fwd");
+        return YUME_OK;
     }
     if (variant == 1 || variant == 2 || variant == 4 || variant == 7) {
         run(variant, 0, Lq);

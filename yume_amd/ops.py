@@ -121,10 +121,9 @@ def gemm_bf16(a, w, bias, out, epi=EPI_BF16, gate=None, gate_stride=0, row_idx=N
     tp, ldt = (None, 0)
     if out_t is not None:
         tp, ldt = _rows(out_t, "out_t")
-    # the scratch is handed over where the stream-K plan can take the shape at all (big launches of the automatic variant)
-    ws = _gemm_workspace(a) if (variant == 0 and M * N >= 256 * 256 * 256 and not torch.cuda.is_current_stream_capturing()) else None
-    if ws is None and variant == 0 and M * N >= 256 * 256 * 256:
-        ws = _gemm_ws.get(_ws_key(a))                     # under capture: only a scratch that exists already (allocated outside)
+    # the scratch is handed over where the split-K plan can take the shape at all (big launches of the automatic variant). Under a stream
+    # capture the first call on the capture stream allocates and zero-fills it inside the capture (the fill is replayed with the graph)
+    ws = _gemm_workspace(a) if (variant == 0 and M * N >= 256 * 256 * 256) else None
     rc = lib.yume_gemm_bf16_ws(ap, lda, wp, ldw, _ptr(bias), M, N, K, epi, op, ldo, _ptr(gate), gate_stride,
                                _ptr(row_idx), tp, ldt, n_split, variant, _ptr(ws), ws.numel() if ws is not None else 0, _stream())
     _lib.check(rc, "yume_gemm_bf16")
