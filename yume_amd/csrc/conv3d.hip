@@ -312,7 +312,10 @@ extern "C" int yume_conv3d_cl(const void* x, const void* cache, int64_t ldc, int
         // (N = 384 / 320 / 640 channels: 75 / 62 / 83 % of their 256-wide N tiles is real work, and the pipeline is worth 2x the gathering
         // 128^2 kernel per padded flop — YUME_CONV_W4_WORTH overrides the 2.0 for A/B runs, 1.25 = the r4 rule)
         static const double w4_worth = [] { const char* v = getenv("YUME_CONV_W4_WORTH"); const double d = v ? atof(v) : 2.0; return d > 0.5 ? d : 2.0; }();
-        const bool big_w4 = big || use_256(p, variant, true, w4_worth);
+        // (at Cout <= 128 the worth-2.0 query is an exact tie whose outcome follows the parity of ceil(M / 128) — a layer could
+        // flip kernels between a grouped and a one-latent pass; those widths now have their own kernel (conv_halo_n.hpp) or stay on the
+        // gathering kernel: the relaxed query needs at least 160 real channels in its 256-wide tile)
+        const bool big_w4 = big || (Cout >= 160 && use_256(p, variant, true, w4_worth));
         if (big_w4 && gemm_w4::conv_w4_applies(p2, cv, st, sh, sw, ups, e2) && (epi != YUME_CONV_EPI_ADD || (add != nullptr && (ldadd % 4) == 0))) {
             static const bool log_on = [] { const char* v = getenv("YUME_CONV_LOG"); return v && atoi(v) != 0; }();
             if (log_on) fprintf(stderr, "[conv3d_cl] w4   M=%lld Cin=%lld Cout=%lld k=%dx%dx%d ups=%d tiles=%d\n", (long long)M, (long long)Cin, (long long)Cout, kt, kh, kw, (int)ups, p2.tiles_m * p2.tiles_n);
