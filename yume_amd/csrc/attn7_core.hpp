@@ -19,6 +19,22 @@ constexpr int QB7 = 256;                  // queries per workgroup
 #ifndef A7_RD
 #define A7_RD 4
 #endif
+// r6 ("swap-free P layout"): the K tile is staged with its rows PERMUTED inside every 32-key block — LDS row m holds key m with
+// bits 2 and 3 exchanged (pure address arithmetic in the loop-invariant LDS-DMA source offsets) — so that a lane's score accumulator holds,
+// per 16-key step, the EIGHT CONSECUTIVE keys 8 (lane >> 5) + 0..7 instead of 4 (lane >> 5) + (0..3) and 8 + 4 (lane >> 5) + (0..3): its
+// exponentials pack straight into the P^T B fragment the V^T image expects. The 8 v_permlane32_swap per block and tile (and the two idle
+// states each needs behind the cvt_pk that feeds it) are gone; the V^T image the QKV epilogue writes is untouched. 0 = the r2-r5 layout (A/B).
+#ifndef A7_SWAPFREE
+#define A7_SWAPFREE 1
+#endif
+// first key (inside a tile) of a lane's accumulator element r of block b, and of the lane half
+#if A7_SWAPFREE
+#define A7_KEY_OF(b, r) (32 * (b) + 16 * ((r) >> 3) + ((r) & 7))
+#define A7_KEYH_SHIFT 3
+#else
+#define A7_KEY_OF(b, r) (32 * (b) + ((r) & 3) + 8 * ((r) >> 2))
+#define A7_KEYH_SHIFT 2
+#endif
 constexpr int RD = A7_RD;                     // V^T fragment ring depth: a fragment is read RD MFMA gaps before its MFMA (8 measured the same)
 constexpr float NEG_BIG = -1.0e30f;
 constexpr float OVERFLOW_LOG2 = 13.0f;       // deferred rescale: exponentials stay below 2^13 against the running base
@@ -157,6 +173,17 @@ __device__ __forceinline__ void sm_piece(Soft& z, const f32x16 (&s)[2], u32x4 (&
     auto pack = [&]() {
         if constexpr (I >= 9) {
             constexpr int g = (I - 9) >> 3, k = (I - 9) & 7;
+#if A7_SWAPFREE
+            // the lane's 8 exponentials of the group ARE its 8 consecutive keys of the k-step: words (p0,p1) (p2,p3) (p4,p5) (p6,p7)
+            if constexpr (k == 0 || k == 1) {          // cvt_pk of the pairs k and 2 + k (k = 0 reads p0, p1, p4, p5; k = 1 reads p2, p3, p6, p7)
+                z.ev = pack_bf16x2(z.p[2 * k], z.p[2 * k + 1]);
+                z.od = pack_bf16x2(z.p[4 + 2 * k], z.p[4 + 2 * k + 1]);
+                z.w0 = z.ev;
+                z.w1 = z.od;
+                pf[g][k] = z.ev;
+                pf[g][2 + k] = z.od;
+            }
+#else
             if constexpr (k == 1 || k == 2) {          // swap of pair k - 1
                 const auto r = __builtin_amdgcn_permlane32_swap(z.ev, z.od, false, false);
                 z.w0 = r[0];
@@ -169,6 +196,7 @@ __device__ __forceinline__ void sm_piece(Soft& z, const f32x16 (&s)[2], u32x4 (&
                 z.ev = pack_bf16x2(z.p[2 * k], z.p[2 * k + 1]);
                 z.od = pack_bf16x2(z.p[4 + 2 * k], z.p[4 + 2 * k + 1]);
             }
+#endif
         }
     };
     auto expo = [&]() {
@@ -187,7 +215,7 @@ __device__ __forceinline__ void sm_piece(Soft& z, const f32x16 (&s)[2], u32x4 (&
 #endif
             if constexpr (MASK) {
                 constexpr int b = e >> 4, r = e & 15;
-                const int key = keyb + 32 * b + (r & 3) + 8 * (r >> 2);
+                const int key = keyb + A7_KEY_OF(b, r);
                 pv = key < Lk ? pv : 0.f;
             }
             z.p[e & 7] = pv;
@@ -260,7 +288,10 @@ __device__ __forceinline__ void dma7_init(Dma7& d, const AttnArgs& p, int h, int
     d.kbase = reinterpret_cast<const char*>(p.K + h * D);
     d.vbase = reinterpret_cast<const char*>(p.Vt + (int64_t)h * D * p.ldvt);
     d.kr = tid >> 4;
-    d.kch = ((tid & 15) ^ (d.kr & 15)) << 4;
+    d.kch = ((tid & 15) ^ (d.kr & 15)) << 4;              // (the swizzle follows the LDS row)
+#if A7_SWAPFREE
+    d.kr = (d.kr & 3) | ((d.kr & 4) << 1) | ((d.kr & 8) >> 1);   // ... the SOURCE row is the LDS row with bits 2 and 3 exchanged (stays inside its 16-row piece)
+#endif
     const int dd = tid >> 3;
     d.vc = (tid & 7) ^ ((dd >> 1) & 7);
 #pragma unroll

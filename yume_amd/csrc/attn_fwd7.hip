@@ -81,7 +81,7 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_kernel_v7(AttnArgs p) {
     cx.lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
     cx.lbase = cx.lds0 + wave * 1024;
     cx.c = p.scale_log2;
-    cx.keyh = 4 * hi;
+    cx.keyh = hi << A7_KEYH_SHIFT;
     cx.Lk = p.Lk;
     cx.wave = wave;
 #pragma unroll

@@ -192,7 +192,7 @@ __device__ __forceinline__ Ctx masked_ctx(const Ctx& cx, int jl_minus_lk) {
     Ctx cm = cx;
     unsigned l;
     asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
-    cm.keyh = (int)((l >> 5) << 2) + jl_minus_lk;
+    cm.keyh = (int)((l >> 5) << A7_KEYH_SHIFT) + jl_minus_lk;
     cm.Lk = 0;
     return cm;
 }
@@ -263,7 +263,7 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_kernel_v8(AttnArgs p, int* cn
     cx.lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
     cx.lbase = cx.lds0 + wave * 1024;
     cx.c = 1.0f;
-    cx.keyh = 4 * hi;
+    cx.keyh = hi << A7_KEYH_SHIFT;
     cx.Lk = p.Lk;
     cx.wave = wave;
 #pragma unroll
