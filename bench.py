@@ -48,8 +48,8 @@ def flops_fwd_5b(L, C=3072, ffn=14336, n=30, Lc=512, cin=48, cout=48):
     return n * blk + 2 * L * (cin * 4) * C + 2 * 512 * (4096 * C + C * C) + 2 * L * (256 * C + C * C + 6 * C * C) + 2 * L * C * 4 * cout
 
 
-PMC_GROUP_FILE = "r3_pmc_gemm_block_shapes_v3.csv"      # tools/run_pmc_gemm.sh: ONE GEMM of the block per process -> one row set per group
-PMC_FILES = ("r5_pmc_traffic_attention_v8.csv", "r4_pmc_traffic_attention_v8.csv", "r3_pmc_traffic_v5.csv", "r2_pmc_traffic_v3.csv", "r2_pmc_dominant_kernels.csv", "r1_pmc_dominant_kernels.csv")
+PMC_GROUP_FILE = "r6_pmc_gemm_block_shapes.csv"   # (r6: refreshed; tools/merge_pmc_gemm.py)      # tools/run_pmc_gemm.sh: ONE GEMM of the block per process -> one row set per group
+PMC_FILES = ("r6_pmc_traffic_attention_v8.csv", "r5_pmc_traffic_attention_v8.csv", "r4_pmc_traffic_attention_v8.csv", "r3_pmc_traffic_v5.csv", "r2_pmc_traffic_v3.csv", "r2_pmc_dominant_kernels.csv", "r1_pmc_dominant_kernels.csv")
 PMC_KERNEL_OF_GROUP = {"attn_self": ("attn_fwd_kernel_v8", "attn_combine_kernel"), "attn_cross": ("attn_fwd_kernel_v2",)}
 
 
