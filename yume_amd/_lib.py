@@ -70,6 +70,10 @@ def load():
             f"{LIB_PATH} is missing: the HIP extension has not been built. "
             "Run `python -c 'import __graft_entry__ as g; g.build()'` (or `python -m yume_amd.build`). "
             "There is no CPU/PyTorch fallback for the yume_amd hot path.")
+    # torch first: its bundled HIP runtime must be the one already in the process when this library's libamdhip64 dependency is
+    # resolved (same SONAME, so the loader shares it). The other order puts two runtimes in one process and the second one finds
+    # no device ("no ROCm-capable device is detected" on the first launch; seen with build() before `import torch`).
+    import torch  # noqa: F401
     lib = ctypes.CDLL(LIB_PATH)
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
