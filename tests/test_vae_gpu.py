@@ -138,6 +138,28 @@ def test_rmsnorm_silu(C):
     assert (ncthw(out) - want).abs().max() <= 2.0 ** -7 * want.abs().max() + 1e-3
 
 
+@pytest.mark.parametrize("C", [96, 160, 192, 320, 384, 640, 48, 8])
+@pytest.mark.parametrize("silu", [True, False])
+def test_rmsnorm_silu_every_lane_busy_form(C, silu):
+    """C / 8 = G * NVL with NVL in {1, 3, 5}: G lanes per row, NVL vectors per lane, several row sets per wave (vae_ops.hip), on a row
+    count that is ragged against every block size; the rows past M must stay untouched."""
+    T, H, W = 1, 263, 251                       # 66013 rows
+    x = rnd(C, T, H, W, seed=11).bfloat16().float()
+    g = 1 + 0.1 * rnd(C, seed=12)
+    want = F.normalize(x, dim=0) * C ** 0.5 * g.view(-1, 1, 1, 1)
+    want = F.silu(want) if silu else want
+    xc = cl(x)
+    out = torch.full((T, H + 1, W, C), 7.0, dtype=torch.bfloat16, device=DEV)
+    V.rmsnorm_silu(xc, g.to(DEV), silu, out[:, :H])
+    assert (ncthw(out[:, :H]) - want).abs().max() <= 2.0 ** -7 * want.abs().max() + 1e-3
+    assert bool((out[:, H] == 7.0).all())
+    beta = 0.2 * rnd(C, seed=13)                 # the additive term of the reference's RMS_norm(bias=True)
+    want_b = F.normalize(x, dim=0) * C ** 0.5 * g.view(-1, 1, 1, 1) + beta.view(-1, 1, 1, 1)
+    want_b = F.silu(want_b) if silu else want_b
+    V.rmsnorm_silu(xc, g.to(DEV), silu, out[:, :H], beta=beta.to(DEV))
+    assert (ncthw(out[:, :H]) - want_b).abs().max() <= 2.0 ** -7 * want_b.abs().max() + 1e-3
+
+
 def test_dupup_avgdown_shortcuts():
     for (Cin, Cout, ft, first) in ((64, 64, 2, False), (64, 32, 2, True), (64, 32, 1, False), (32, 32, 2, True)):
         T, H, W = 3, 4, 5

@@ -64,6 +64,179 @@ __global__ __launch_bounds__(256) void rmsnorm_silu_kernel(const unsigned short*
     }
 }
 
+// ---- RMS_norm (+SiLU), every lane busy: G lanes (a power of two) own one row and NVL 16-byte vectors of it each (G * NVL = C / 8), 64 / G rows
+// per wave, RI such row sets per wave. The kernel above is bound by VALU issue, not by HBM (3.4-4.0 TB/s at every VAE level with a quarter
+// to three eighths of the lanes idle: 12 of 16 lanes at 96 channels, 20 of 32 at 160; the IEEE division of its SiLU is ~10 issue slots per
+// element): here 96 / 192 / 384 channels run as G = 4 / 8 / 16 with NVL = 3 and 160 / 320 / 640 as NVL = 5, SiLU is x * rcp(1 + exp2(-x log2 e))
+// (one v_exp_f32, one v_rcp_f32: 1 ulp, below the bf16 rounding of the result) and the arithmetic runs two elements per issue on the
+// packed fp32 ALU.
+__device__ __forceinline__ f32x2_t silu2_fast(f32x2_t x) {
+    const f32x2_t k = {-1.4426950408889634f, -1.4426950408889634f}, one = {1.0f, 1.0f};
+    const f32x2_t u = x * k;
+    const f32x2_t e = {__builtin_amdgcn_exp2f(u[0]), __builtin_amdgcn_exp2f(u[1])};
+    const f32x2_t d = e + one;
+    const f32x2_t r = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+    return x * r;
+}
+
+template <int G, int NVL, int RI>
+__global__ __launch_bounds__(256) void rmsnorm_silu_g_kernel(const unsigned short* __restrict__ x, int64_t ldx, int64_t M, int C,
+                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                             int silu_on, unsigned short* __restrict__ y, int64_t ldy) {
+    constexpr int RPW = 64 / G;
+    const int lane = threadIdx.x & 63;
+    const int sub = lane % G;
+    const int64_t row0 = (int64_t)blockIdx.x * (RI * 4 * RPW) + (threadIdx.x >> 6) * RPW + lane / G;
+    u32x4 v[RI][NVL];
+#pragma unroll
+    for (int r = 0; r < RI; ++r) {
+        const int64_t row = row0 + (int64_t)r * (4 * RPW);
+#pragma unroll
+        for (int i = 0; i < NVL; ++i) {
+            v[r][i] = u32x4{0u, 0u, 0u, 0u};
+            if (row < M) v[r][i] = *reinterpret_cast<const u32x4*>(x + row * ldx + 8 * (sub + i * G));
+        }
+    }
+    float inv[RI];
+    const float sqrt_c = sqrtf((float)C);
+#pragma unroll
+    for (int r = 0; r < RI; ++r) {
+        f32x2_t s2 = {0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < NVL; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const f32x2_t f = {__uint_as_float(v[r][i][j] << 16), __uint_as_float(v[r][i][j] & 0xffff0000u)};
+                s2 += f * f;
+            }
+        float ss = s2[0] + s2[1];
+#pragma unroll
+        for (int o = G / 2; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+        inv[r] = sqrt_c / fmaxf(sqrtf(ss), 1e-12f);
+    }
+#pragma unroll
+    for (int i = 0; i < NVL; ++i) {
+        const int c0 = 8 * (sub + i * G);
+        f32x2_t g[4], b[4];
+        {
+            const f32x4 g0 = *reinterpret_cast<const f32x4*>(gamma + c0), g1 = *reinterpret_cast<const f32x4*>(gamma + c0 + 4);
+            g[0] = f32x2_t{g0[0], g0[1]}; g[1] = f32x2_t{g0[2], g0[3]}; g[2] = f32x2_t{g1[0], g1[1]}; g[3] = f32x2_t{g1[2], g1[3]};
+            f32x4 b0 = f32x4{0.f, 0.f, 0.f, 0.f}, b1 = b0;
+            if (beta) {
+                b0 = *reinterpret_cast<const f32x4*>(beta + c0);
+                b1 = *reinterpret_cast<const f32x4*>(beta + c0 + 4);
+            }
+            b[0] = f32x2_t{b0[0], b0[1]}; b[1] = f32x2_t{b0[2], b0[3]}; b[2] = f32x2_t{b1[0], b1[1]}; b[3] = f32x2_t{b1[2], b1[3]};
+        }
+#pragma unroll
+        for (int r = 0; r < RI; ++r) {
+            const int64_t row = row0 + (int64_t)r * (4 * RPW);
+            if (row >= M) continue;
+            const f32x2_t iv = {inv[r], inv[r]};
+            u32x4 w;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const f32x2_t f = {__uint_as_float(v[r][i][j] << 16), __uint_as_float(v[r][i][j] & 0xffff0000u)};
+                f32x2_t o = (f * iv) * g[j] + b[j];
+                if (silu_on) o = silu2_fast(o);
+                w[j] = pack_bf16x2(o[0], o[1]);
+            }
+            *reinterpret_cast<u32x4*>(y + row * ldy + 8 * (sub + i * G)) = w;
+        }
+    }
+}
+
+// ---- RMS_norm (+SiLU), flat form for contiguous rows (ldx == ldy == C): a wave owns NVL * 64 consecutive 16-byte vectors = R = NVL * 64 / NVEC
+// whole rows (NVEC = C / 8 vectors per row) and lane l takes vectors l, 64 + l, ... of that chunk, so every load and every store instruction
+// of the wave is one contiguous KiB whatever the row length (the grouped form above reads a 96- or 160-channel row as 64-byte pieces,
+// 16 rows apart per instruction: 4.0-4.4 TB/s against 5.7 at 192 / 384 channels). The sum of squares crosses lanes through the wave's own
+// 4 * NVL * 64 bytes of LDS: every lane leaves the partial sum of each of its vectors, lane r < R adds row r's NVEC partials in index order and
+// leaves the row's scale, every lane picks up the scale of the row of each of its vectors. gamma (and beta) belong to (lane, i) alone
+// (a chunk starts on a row boundary), so they stay in registers across the RI chunks of a wave.
+template <int NVEC, int NVL, int RI, bool SILU, bool BETA>
+__global__ __launch_bounds__(256) void rmsnorm_silu_flat_kernel(const unsigned short* __restrict__ x, int64_t M, const float* __restrict__ gamma,
+                                                                const float* __restrict__ beta, unsigned short* __restrict__ y) {
+    constexpr int CH = NVL * 64;                 // vectors per chunk
+    constexpr int R = CH / NVEC;                 // rows per chunk
+    static_assert(R * NVEC == CH && R <= 64 && (NVEC % 4) == 0, "a chunk is whole rows");
+    __shared__ __attribute__((aligned(16))) float part[4][RI][CH];
+    __shared__ float scale[4][RI][R];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t total = M * NVEC;
+    const int64_t vb0 = ((int64_t)blockIdx.x * 4 + wave) * RI * CH;
+    u32x4 v[RI][NVL];
+#pragma unroll
+    for (int r = 0; r < RI; ++r)
+#pragma unroll
+        for (int i = 0; i < NVL; ++i) {
+            const int64_t f = vb0 + r * CH + i * 64 + lane;
+            v[r][i] = u32x4{0u, 0u, 0u, 0u};
+            if (f < total) v[r][i] = *reinterpret_cast<const u32x4*>(x + 8 * f);
+        }
+#pragma unroll
+    for (int r = 0; r < RI; ++r)
+#pragma unroll
+        for (int i = 0; i < NVL; ++i) {
+            f32x2_t s2 = {0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const f32x2_t f = {__uint_as_float(v[r][i][j] << 16), __uint_as_float(v[r][i][j] & 0xffff0000u)};
+                s2 += f * f;
+            }
+            part[wave][r][i * 64 + lane] = s2[0] + s2[1];
+        }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const float sqrt_c = sqrtf((float)(NVEC * 8));
+    if (lane < R) {
+#pragma unroll
+        for (int r = 0; r < RI; ++r) {
+            float ss = 0.f;
+#pragma unroll
+            for (int k = 0; k < NVEC / 4; ++k) {
+                const f32x4 q = *reinterpret_cast<const f32x4*>(&part[wave][r][lane * NVEC + 4 * k]);
+                ss += (q[0] + q[1]) + (q[2] + q[3]);
+            }
+            scale[wave][r][lane] = sqrt_c / fmaxf(sqrtf(ss), 1e-12f);
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int i = 0; i < NVL; ++i) {
+        const int fl = i * 64 + lane;
+        const int rowl = fl / NVEC, c0 = 8 * (fl % NVEC);
+        f32x2_t g[4], b[4];
+        {
+            const f32x4 g0 = *reinterpret_cast<const f32x4*>(gamma + c0), g1 = *reinterpret_cast<const f32x4*>(gamma + c0 + 4);
+            g[0] = f32x2_t{g0[0], g0[1]}; g[1] = f32x2_t{g0[2], g0[3]}; g[2] = f32x2_t{g1[0], g1[1]}; g[3] = f32x2_t{g1[2], g1[3]};
+            if (BETA) {
+                const f32x4 b0 = *reinterpret_cast<const f32x4*>(beta + c0), b1 = *reinterpret_cast<const f32x4*>(beta + c0 + 4);
+                b[0] = f32x2_t{b0[0], b0[1]}; b[1] = f32x2_t{b0[2], b0[3]}; b[2] = f32x2_t{b1[0], b1[1]}; b[3] = f32x2_t{b1[2], b1[3]};
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < RI; ++r) {
+            const int64_t f = vb0 + r * CH + fl;
+            if (f >= total) continue;
+            const float inv = scale[wave][r][rowl];
+            const f32x2_t iv = {inv, inv};
+            u32x4 w;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const f32x2_t e = {__uint_as_float(v[r][i][j] << 16), __uint_as_float(v[r][i][j] & 0xffff0000u)};
+                f32x2_t o = (e * iv) * g[j];
+                if (BETA) o += b[j];
+                if (SILU) o = silu2_fast(o);
+                w[j] = pack_bf16x2(o[0], o[1]);
+            }
+            *reinterpret_cast<u32x4*>(y + 8 * f) = w;
+        }
+    }
+}
+
 // ---- DupUp3D add: one thread per (output position, 8 output channels) ----
 __global__ __launch_bounds__(256) void dupup_add_kernel(const unsigned short* __restrict__ x, int64_t ldx, int Tin, int Hin,
                                                         int Win, int Cin, unsigned short* __restrict__ y, int64_t ldy,
@@ -298,13 +471,51 @@ extern "C" int yume_vae_rmsnorm_silu(const void* x, int64_t ldx, int64_t M, int6
 #define LAUNCH_RMS(LPR, NV)                                                                                          \
     hipLaunchKernelGGL((rmsnorm_silu_kernel<LPR, NV>), dim3((unsigned)((M + 4 * (64 / LPR) - 1) / (4 * (64 / LPR)))), \
                        dim3(256), 0, st, xp, ldx, M, (int)C, gamma, beta, silu_on, yp, ldy)
-    if (nvec <= 8) LAUNCH_RMS(8, 1);
+    // the every-lane-busy form where C / 8 = G * NVL with G a power of two <= 64 and NVL in {1, 3, 5} (YUME_VAE_NORM_G=0: the form above)
+    static const bool grouped = [] { const char* v = getenv("YUME_VAE_NORM_G"); return !v || atoi(v) != 0; }();
+    int G = 1;
+    while (G < 64 && (nvec % (2 * G)) == 0) G *= 2;
+    const int nvl = nvec / G;
+#define LAUNCH_RMS_G(GG, NVL, RI)                                                                                                    \
+    hipLaunchKernelGGL((rmsnorm_silu_g_kernel<GG, NVL, RI>), dim3((unsigned)((M + RI * 4 * (64 / GG) - 1) / (RI * 4 * (64 / GG)))), \
+                       dim3(256), 0, st, xp, ldx, M, (int)C, gamma, beta, silu_on, yp, ldy)
+#define LAUNCH_RMS_GN(NVL, RI)                                                                              \
+    switch (G) {                                                                                            \
+        case 1: LAUNCH_RMS_G(1, NVL, RI); break;   case 2: LAUNCH_RMS_G(2, NVL, RI); break;                \
+        case 4: LAUNCH_RMS_G(4, NVL, RI); break;   case 8: LAUNCH_RMS_G(8, NVL, RI); break;                \
+        case 16: LAUNCH_RMS_G(16, NVL, RI); break; case 32: LAUNCH_RMS_G(32, NVL, RI); break;              \
+        default: LAUNCH_RMS_G(64, NVL, RI); break;                                                          \
+    }
+    // contiguous rows of 96 / 192 / 384 or 160 / 320 / 640 channels: the flat form (YUME_VAE_NORM_FLAT=0: the grouped one)
+    static const bool flat = [] { const char* v = getenv("YUME_VAE_NORM_FLAT"); return !v || atoi(v) != 0; }();
+#define LAUNCH_RMS_F(NVEC, NVL, RI)                                                                                                         \
+    do {                                                                                                                                    \
+        const unsigned nb = (unsigned)((M * NVEC + (int64_t)4 * RI * NVL * 64 - 1) / ((int64_t)4 * RI * NVL * 64));                         \
+        if (silu_on && !beta) hipLaunchKernelGGL((rmsnorm_silu_flat_kernel<NVEC, NVL, RI, true, false>), dim3(nb), dim3(256), 0, st, xp, M, gamma, beta, yp); \
+        else if (silu_on) hipLaunchKernelGGL((rmsnorm_silu_flat_kernel<NVEC, NVL, RI, true, true>), dim3(nb), dim3(256), 0, st, xp, M, gamma, beta, yp);      \
+        else if (!beta) hipLaunchKernelGGL((rmsnorm_silu_flat_kernel<NVEC, NVL, RI, false, false>), dim3(nb), dim3(256), 0, st, xp, M, gamma, beta, yp);      \
+        else hipLaunchKernelGGL((rmsnorm_silu_flat_kernel<NVEC, NVL, RI, false, true>), dim3(nb), dim3(256), 0, st, xp, M, gamma, beta, yp);                  \
+    } while (0)
+    const bool contiguous = ldx == C && ldy == C;
+    if (grouped && flat && contiguous && nvec == 12) LAUNCH_RMS_F(12, 3, 2);
+    else if (grouped && flat && contiguous && nvec == 24) LAUNCH_RMS_F(24, 3, 2);
+    else if (grouped && flat && contiguous && nvec == 48) LAUNCH_RMS_F(48, 3, 2);
+    else if (grouped && flat && contiguous && nvec == 20) LAUNCH_RMS_F(20, 5, 1);
+    else if (grouped && flat && contiguous && nvec == 40) LAUNCH_RMS_F(40, 5, 1);
+    else if (grouped && flat && contiguous && nvec == 80) LAUNCH_RMS_F(80, 5, 1);
+    else if (grouped && nvl == 1) { LAUNCH_RMS_GN(1, 4); }
+    else if (grouped && nvl == 3) { LAUNCH_RMS_GN(3, 2); }
+    else if (grouped && nvl == 5) { LAUNCH_RMS_GN(5, 1); }
+    else if (nvec <= 8) LAUNCH_RMS(8, 1);
     else if (nvec <= 16) LAUNCH_RMS(16, 1);
     else if (nvec <= 32) LAUNCH_RMS(32, 1);
     else if (nvec <= 64) LAUNCH_RMS(64, 1);
     else if (nvec <= 128) LAUNCH_RMS(64, 2);
     else if (nvec <= 256) LAUNCH_RMS(64, 4);
     else LAUNCH_RMS(64, 8);
+#undef LAUNCH_RMS_F
+#undef LAUNCH_RMS_GN
+#undef LAUNCH_RMS_G
 #undef LAUNCH_RMS
     YUME_CHECK_LAUNCH("vae_rmsnorm_silu");
     return YUME_OK;
