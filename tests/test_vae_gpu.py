@@ -160,6 +160,44 @@ def test_rmsnorm_silu_every_lane_busy_form(C, silu):
     assert (ncthw(out[:, :H]) - want_b).abs().max() <= 2.0 ** -7 * want_b.abs().max() + 1e-3
 
 
+@pytest.mark.parametrize("case", [(64, 64, 2, 2, True), (128, 64, 2, 2, False), (128, 64, 1, 2, False), (128, 32, 2, 2, True), (40, 40, 2, 2, False)])
+def test_dupup_add_per_line_form_matches_the_general_kernel(case, monkeypatch):
+    """vae_ops.hip dupup_add_lines_kernel (Q = Cin / Cout in {1, 2, 4}; a vector count per pixel that is not a power of two in the last case)
+    against the oracle's DupUp3D and, bit for bit, against the general kernel on the same tensors."""
+    Cin, Cout, ft, fs, first = case
+    T, H, W = 3, 5, 37
+    x = rnd(Cin, T, H, W, seed=21).bfloat16().float()
+    want_s = ovae.dup_up(x, Cout, ft, fs, first)
+    y = rnd(*want_s.shape, seed=22).bfloat16().float()
+    outs = []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("YUME_VAE_SHORTCUT_LINES", flag)
+        yc = cl(y)
+        V.dupup_add(cl(x), yc, ft, fs, (ft - 1) if first else 0)
+        outs.append(yc)
+    assert (ncthw(outs[0]) - (y + want_s)).abs().max() <= 2.0 ** -7 * (y + want_s).abs().max()
+    assert torch.equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize("case", [(32, 32, 1, 2, 3), (32, 64, 2, 2, 4), (32, 64, 2, 2, 1), (64, 64, 1, 1, 2), (160, 320, 1, 2, 2), (16, 64, 2, 2, 5),
+                                  (8, 64, 2, 2, 3)])
+def test_avgdown_add_per_line_form_matches_the_general_kernel(case, monkeypatch):
+    """vae_ops.hip avgdown_add_lines_kernel (RR = F / G in {1, 2, 4, 8}) against the oracle's AvgDown3D and, bit for bit, the general kernel."""
+    Cin, Cout, ft, fs, T = case
+    H, W = 6, 38
+    x = rnd(Cin, T, H, W, seed=23).bfloat16().float()
+    want_s = ovae.avg_down(x, Cout, ft, fs)
+    y = rnd(*want_s.shape, seed=24).bfloat16().float()
+    outs = []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("YUME_VAE_SHORTCUT_LINES", flag)
+        yc = cl(y)
+        V.avgdown_add(cl(x), yc, ft, fs)
+        outs.append(yc)
+    assert (ncthw(outs[0]) - (y + want_s)).abs().max() <= 2.0 ** -7 * (y + want_s).abs().max() + 1e-6
+    assert torch.equal(outs[0], outs[1])
+
+
 def test_dupup_avgdown_shortcuts():
     for (Cin, Cout, ft, first) in ((64, 64, 2, False), (64, 32, 2, True), (64, 32, 1, False), (32, 32, 2, True)):
         T, H, W = 3, 4, 5

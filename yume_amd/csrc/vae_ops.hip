@@ -304,6 +304,111 @@ __global__ __launch_bounds__(256) void avgdown_add_kernel(const unsigned short* 
     }
 }
 
+// ---- the two shortcut adds again, without the per-thread 64-bit div / mod chains and 2-byte gathers of the kernels above (those ran at
+// 2.1 TB/s on the 6.5 GB read-modify-write of the Wan2.2 decoder's last DupUp3D: bound by integer VALU work, not by HBM) ----
+// One grid row per output line (frame, image row): the frame / row / phase arithmetic is per workgroup; a thread owns 8 output channels of one
+// output pixel and finds its pixel by one 32-bit division (a shift when the vector count per pixel is a power of two).
+// DupUp3D where repeats | F (Cin >= Cout, Q = Cin / Cout in {1, 2, 4}): output channel oc reads input channel oc * Q + phase / repeats, so the 8
+// output channels of a thread come out of Q consecutive 16-byte vectors of the input pixel.
+template <int Q>
+__global__ __launch_bounds__(256) void dupup_add_lines_kernel(const unsigned short* __restrict__ x, int64_t ldx, int Hin, int Win,
+                                                              unsigned short* __restrict__ y, int64_t ldy, int Ho, int Wo, int cv, int cv_shift,
+                                                              int ft, int fs, int toff, int rep_shift) {
+    const int line = blockIdx.y;
+    const int to = line / Ho, ho = line - to * Ho;
+    const int tt = to + toff, ti = tt / ft, a = tt - ti * ft;
+    const int hi = ho / fs, b = ho - hi * fs;
+    const unsigned short* xl = x + ((int64_t)ti * Hin + hi) * Win * ldx;
+    unsigned short* yl = y + (int64_t)line * Wo * ldy;
+    const int n = Wo * cv;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const int wo = cv_shift >= 0 ? (i >> cv_shift) : (i / cv);
+        const int c8 = i - wo * cv;
+        const int wi = wo / fs, c = wo - wi * fs;
+        const int off = (((a * fs + b) * fs + c) >> rep_shift);           // < Q
+        const unsigned short* xr = xl + (int64_t)wi * ldx + 8 * Q * c8;
+        unsigned short* yr = yl + (int64_t)wo * ldy + 8 * c8;
+        u32x4 xv[Q];
+#pragma unroll
+        for (int k = 0; k < Q; ++k) xv[k] = *reinterpret_cast<const u32x4*>(xr + 8 * k);
+        u32x4 yv = *reinterpret_cast<const u32x4*>(yr);
+        float o[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            // element j * Q + off of the Q vectors: dword (j * Q + off) >> 1, half (j * Q + off) & 1
+            unsigned int w;
+            if (Q == 1) w = xv[0][j >> 1];
+            else if (Q == 2) w = xv[j >> 2][j & 3];
+            else w = (off >> 1) ? xv[j >> 1][2 * (j & 1) + 1] : xv[j >> 1][2 * (j & 1)];
+            const bool hi_half = Q == 1 ? (j & 1) != 0 : (off & 1) != 0;
+            const float xf = __uint_as_float(hi_half ? (w & 0xffff0000u) : (w << 16));
+            const unsigned int yw = yv[j >> 1];
+            o[j] = __uint_as_float((j & 1) ? (yw & 0xffff0000u) : (yw << 16)) + xf;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) yv[j] = pack_bf16x2(o[2 * j], o[2 * j + 1]);
+        *reinterpret_cast<u32x4*>(yr) = yv;
+    }
+}
+
+// AvgDown3D where G | F (RR = F / G in {1, 2, 4, 8}): output channel oc averages the G phases (oc % RR) * G ... of input channel oc / RR, so the 8
+// output channels of a thread read 8 / RR consecutive input channels at each of the F phase positions; the phases are added in the order
+// of the kernel above (same bits).
+template <int RR>
+__global__ __launch_bounds__(256) void avgdown_add_lines_kernel(const unsigned short* __restrict__ x, int64_t ldx, int Hin, int Win,
+                                                                unsigned short* __restrict__ y, int64_t ldy, int Ho, int Wo, int cv, int cv_shift,
+                                                                int ft, int fs, int G, int padt) {
+    const int line = blockIdx.y;
+    const int to = line / Ho, ho = line - to * Ho;
+    unsigned short* yl = y + (int64_t)line * Wo * ldy;
+    const int n = Wo * cv, F = ft * fs * fs;
+    const float inv_g = (float)G;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const int wo = cv_shift >= 0 ? (i >> cv_shift) : (i / cv);
+        const int c8 = i - wo * cv;
+        float acc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+        for (int p = 0; p < F; ++p) {
+            const int c = p % fs, b = (p / fs) % fs, a = p / (fs * fs);
+            const int ti = to * ft + a - padt;
+            if (ti < 0) continue;
+            const int cls = p / G;
+            const unsigned short* xr = x + (((int64_t)ti * Hin + ho * fs + b) * Win + wo * fs + c) * ldx + (8 / RR) * c8;
+            float e[8 / RR];
+            if (RR == 1) {
+                const u32x4 v = *reinterpret_cast<const u32x4*>(xr);
+#pragma unroll
+                for (int j = 0; j < 8 / RR; ++j) e[j] = __uint_as_float((j & 1) ? (v[(j >> 1) & 3] & 0xffff0000u) : (v[(j >> 1) & 3] << 16));
+            } else if (RR == 2) {
+                const u32x2 v = *reinterpret_cast<const u32x2*>(xr);
+#pragma unroll
+                for (int j = 0; j < 8 / RR; ++j) e[j] = __uint_as_float((j & 1) ? (v[(j >> 1) & 1] & 0xffff0000u) : (v[(j >> 1) & 1] << 16));
+            } else if (RR == 4) {
+                const unsigned int v = *reinterpret_cast<const unsigned int*>(xr);
+                e[0] = __uint_as_float(v << 16);
+                e[(8 / RR) - 1] = __uint_as_float(v & 0xffff0000u);
+            } else {
+                e[0] = bf16_to_f32(*xr);
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if ((j % RR) == cls) acc[j] += e[j / RR];
+        }
+        unsigned short* yr = yl + (int64_t)wo * ldy + 8 * c8;
+        u32x4 yv = *reinterpret_cast<const u32x4*>(yr);
+        float o[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const unsigned int yw = yv[j >> 1];
+            o[j] = __uint_as_float((j & 1) ? (yw & 0xffff0000u) : (yw << 16)) + acc[j] / inv_g;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) yv[j] = pack_bf16x2(o[2 * j], o[2 * j + 1]);
+        *reinterpret_cast<u32x4*>(yr) = yv;
+    }
+}
+
 // ---- row softmax: one workgroup per row, three passes over a (cache resident) fp32 row ----
 __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ S, int64_t lds_, int n, float scale,
                                                            unsigned short* __restrict__ P, int64_t ldp) {
@@ -528,6 +633,28 @@ extern "C" int yume_vae_dupup_add(const void* x, int64_t ldx, int64_t Tin, int64
     YUME_REQUIRE((Cout * ft * fs * fs) % Cin == 0, "vae_dupup_add: Cout*factor must be a multiple of Cin");
     YUME_REQUIRE(toff >= 0 && To + toff <= Tin * ft, "vae_dupup_add: frame range");
     const int64_t total = To * Hin * fs * Win * fs * (Cout / 8);
+    {
+        // the per-line form: repeats = Cout * F / Cin a power of two dividing F (Q = Cin / Cout in {1, 2, 4}); YUME_VAE_SHORTCUT_LINES=0: the form below
+        const char* ev = getenv("YUME_VAE_SHORTCUT_LINES");
+        const int64_t F = (int64_t)ft * fs * fs, repeats = Cout * F / Cin;
+        const int64_t Ho = Hin * fs, Wo = Win * fs, cv = Cout / 8, lines = To * Ho;
+        const bool pow2 = repeats > 0 && (repeats & (repeats - 1)) == 0;
+        const int64_t Q = pow2 && (F % repeats) == 0 ? F / repeats : 0;
+        if ((!ev || atoi(ev) != 0) && (Q == 1 || Q == 2 || Q == 4) && (ldx % 8) == 0 && Cin == Cout * Q && lines > 0 && lines < 65536 &&
+            Wo * cv < (1ll << 30)) {
+            int rep_shift = 0, cv_shift = -1;
+            while ((1ll << rep_shift) < repeats) ++rep_shift;
+            if ((cv & (cv - 1)) == 0) { cv_shift = 0; while ((1ll << cv_shift) < cv) ++cv_shift; }
+            const unsigned gx = (unsigned)((Wo * cv + 1023) / 1024);      // four pixels-by-8-channels per thread
+#define LAUNCH_DUP(QQ)                                                                                                                          \
+    hipLaunchKernelGGL(dupup_add_lines_kernel<QQ>, dim3(gx, (unsigned)lines), dim3(256), 0, (hipStream_t)stream, (const unsigned short*)x, ldx, \
+                       (int)Hin, (int)Win, (unsigned short*)y, ldy, (int)Ho, (int)Wo, (int)cv, cv_shift, ft, fs, toff, rep_shift)
+            if (Q == 1) LAUNCH_DUP(1); else if (Q == 2) LAUNCH_DUP(2); else LAUNCH_DUP(4);
+#undef LAUNCH_DUP
+            YUME_CHECK_LAUNCH("vae_dupup_add");
+            return YUME_OK;
+        }
+    }
     hipLaunchKernelGGL(dupup_add_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const unsigned short*)x,
                        ldx, (int)Tin, (int)Hin, (int)Win, (int)Cin, (unsigned short*)y, ldy, (int)To, (int)Cout, ft, fs, toff);
     YUME_CHECK_LAUNCH("vae_dupup_add");
@@ -541,6 +668,26 @@ extern "C" int yume_vae_avgdown_add(const void* x, int64_t ldx, int64_t Tin, int
     YUME_REQUIRE((Cin * ft * fs * fs) % Cout == 0, "vae_avgdown_add: Cin*factor must be a multiple of Cout");
     const int64_t padt = (ft - Tin % ft) % ft;
     const int64_t total = ((Tin + padt) / ft) * (Hin / fs) * (Win / fs) * Cout;
+    {
+        // the per-line form: G = Cin * F / Cout dividing F (RR = F / G in {1, 2, 4, 8}), 8 output channels per thread
+        const char* ev = getenv("YUME_VAE_SHORTCUT_LINES");
+        const int64_t F = (int64_t)ft * fs * fs, G = Cin * F / Cout;
+        const int64_t To = (Tin + padt) / ft, Ho = Hin / fs, Wo = Win / fs, cv = Cout / 8, lines = To * Ho;
+        const int64_t RR = G > 0 && (F % G) == 0 ? F / G : 0;
+        if ((!ev || atoi(ev) != 0) && (RR == 1 || RR == 2 || RR == 4 || RR == 8) && (Cout % 8) == 0 && (ldy % 8) == 0 && (ldx % 8) == 0 &&
+            Cin * RR == Cout && lines > 0 && lines < 65536 && Wo * cv < (1ll << 30)) {
+            int cv_shift = -1;
+            if ((cv & (cv - 1)) == 0) { cv_shift = 0; while ((1ll << cv_shift) < cv) ++cv_shift; }
+            const unsigned gx = (unsigned)((Wo * cv + 1023) / 1024);      // four pixels-by-8-channels per thread
+#define LAUNCH_AVG(R_)                                                                                                                            \
+    hipLaunchKernelGGL(avgdown_add_lines_kernel<R_>, dim3(gx, (unsigned)lines), dim3(256), 0, (hipStream_t)stream, (const unsigned short*)x, ldx, \
+                       (int)Hin, (int)Win, (unsigned short*)y, ldy, (int)Ho, (int)Wo, (int)cv, cv_shift, ft, fs, (int)G, (int)padt)
+            if (RR == 1) LAUNCH_AVG(1); else if (RR == 2) LAUNCH_AVG(2); else if (RR == 4) LAUNCH_AVG(4); else LAUNCH_AVG(8);
+#undef LAUNCH_AVG
+            YUME_CHECK_LAUNCH("vae_avgdown_add");
+            return YUME_OK;
+        }
+    }
     hipLaunchKernelGGL(avgdown_add_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const unsigned short*)x,
                        ldx, (int)Tin, (int)Hin, (int)Win, (int)Cin, (unsigned short*)y, ldy, (int)Cout, ft, fs);
     YUME_CHECK_LAUNCH("vae_avgdown_add");
