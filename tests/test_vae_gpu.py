@@ -217,6 +217,25 @@ def test_dupup_avgdown_shortcuts():
         assert (ncthw(yc) - (y + want_s)).abs().max() <= 2.0 ** -7 * (y + want_s).abs().max() + 1e-3
 
 
+@pytest.mark.parametrize("n,lds,ldp", [(100, 100, 128), (101, 104, 128), (3520, 3520, 3520), (8160, 8160, 8192), (8163, 8164, 8256), (9000, 9000, 9024)])
+def test_softmax_rows_register_window_and_general_kernel(n, lds, ldp, monkeypatch):
+    """vae_ops.hip softmax_rows_reg_kernel (the row read once; n <= 8192) against torch.softmax, the padding columns zero; the three-pass
+    kernel (YUME_VAE_SOFTMAX_REG=0, and n = 9000 whatever the switch) agrees to bf16 rounding."""
+    rows = 19
+    s = torch.zeros(rows, lds)
+    s[:, :n] = rnd(rows, n, seed=31) * 5
+    s[:, n:] = 1e9                                    # the columns between n and lds are not part of the row
+    want = torch.softmax(s[:, :n] * 0.25, dim=-1)
+    got = []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("YUME_VAE_SOFTMAX_REG", flag)
+        p = torch.full((rows, ldp), 7.0, dtype=torch.bfloat16, device=DEV)
+        V.softmax_rows(s.to(DEV), n, 0.25, p)
+        assert (p.cpu().float()[:, :n] - want).abs().max() <= 2.0 ** -8 * want.max() + 1e-6 and (p.cpu()[:, n:] == 0).all()
+        got.append(p)
+    assert (got[0].float() - got[1].float()).abs().max() <= 2.0 ** -7 * float(got[1].float().max())
+
+
 def test_softmax_rows_and_layouts():
     s = rnd(37, 100, seed=1) * 5
     p = torch.full((37, 128), 7.0, dtype=torch.bfloat16, device=DEV)
