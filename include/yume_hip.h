@@ -151,6 +151,9 @@ int yume_gemm_bf16_ws(const void* A, int64_t lda, const void* W, int64_t ldw, co
  *   if rope: head-wise (head_dim D, pairs (2j,2j+1)):  (y0,y1) <- (y0*cos - y1*sin, y0*sin + y1*cos)
  *            with rope = fp32 [T, D/2, 2] (cos, sin) per token, shared by all heads.
  * w: fp32 [nparts, C].   C % 512 == 0, D == 128.
+ * eps < 0: the rows are NOT normalised — y = x * w_p[c], then RoPE: the reference's nn.Identity in place of WanRMSNorm when a model is
+ *   built with qk_norm=False (wan23/modules/model.py:175-176); w then carries ones (times the attention scale on the q side). The same
+ *   holds for yume_rmsnorm_rows_periodic.
  */
 int yume_rmsnorm_rope(void* buf, int64_t ld, int64_t T, int64_t C, int nparts,
                       const float* w, float eps, const float* rope, int64_t D, void* stream);

@@ -136,6 +136,34 @@ def test_deep_framepack_levels_vs_oracle(family, F, lfz):
     assert e <= 1.5e-2
 
 
+@pytest.mark.parametrize("family,F,lfz,packed", [("wan23", 15, 8, True), ("wan23", 3, 8, False), ("wan", 16, 9, True)])
+def test_model_without_qk_norm_vs_oracle(family, F, lfz, packed):
+    """WanModel(qk_norm=False) (reference wan23/modules/model.py:175-176: nn.Identity for norm_q / norm_k): the engine runs the RoPE / scale
+    kernel with its normalisation off (eps < 0 at the C-ABI); the oracle is pinned to the live reference for the same configuration in
+    tests/test_oracle_dit.py. The state dict has no norm_q / norm_k keys and loads strictly."""
+    from yume_amd import framepack
+    cfg = dict(synth.tiny_cfg(family, layers=2), qk_norm=False)
+    sd = synth.make_dit_state_dict(cfg, family, seed=61)
+    inp = synth.make_dit_inputs(cfg, family, F, 10, 12, n_text=9, seed=62)
+    if packed:
+        plan = framepack.pack_plan(F, 10, 12, lfz, (F - 9) if family == "wan" else None)
+        L = plan.seq_len
+    else:
+        L = F * 5 * 6
+    if family == "wan23":
+        t = (torch.cat([torch.zeros(plan.n_hist_tok), torch.full((plan.n_new_tok,), 333.25)]).unsqueeze(0).double() if packed
+             else torch.tensor([250.0]))
+        want = odit.forward_wan23(sd, cfg, inp["x"], t, inp["context"], L, lfz, packed)
+    else:
+        t = torch.tensor([250.0])
+        want = odit.forward_wan(sd, cfg, inp["x"], t, inp["context"], L, inp["clip_fea"][0], inp["y"], 0.6, lfz)
+    m = build_model(family, cfg, sd)
+    got = run_model(m, family, dict(inputs=inp, t=t, seq_len=L, lfz=lfz, packed=packed))
+    e = rel_l2(got, want)
+    print(f"{family} qk_norm=False F={F}: L={L} rel-L2 {e:.3e}")
+    assert got.shape == want.shape and e <= 1.5e-2
+
+
 def test_per_token_timesteps_on_the_plain_path():
     """wan23 plain path with an arbitrary per-token t [1, seq_len] (textimage2video's i2v masks the first frame to t=0)."""
     cfg = synth.tiny_cfg("wan23", layers=1)

@@ -78,6 +78,34 @@ def test_oracle_matches_live_reference(family, F, lfz, packed):
     assert (got - want).abs().max().item() <= 2e-5
 
 
+@pytest.mark.skipif(not ref_import.available(), reason="reference tree not present (GPU box)")
+@pytest.mark.parametrize("family,F,lfz,packed", [("wan23", 15, 8, True), ("wan23", 3, 8, False), ("wan", 16, 9, True)])
+def test_oracle_matches_live_reference_without_qk_norm(family, F, lfz, packed):
+    """qk_norm=False (wan23/modules/model.py:175-176, wan/modules/model.py WanSelfAttention / WanI2VCrossAttention: nn.Identity in place of
+    WanRMSNorm — no norm_q / norm_k / norm_k_img weights in the state dict): the oracle passes q / k through, like the reference."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    from make_golden import build_reference, run_reference, token_count
+    cfg = dict(synth.tiny_cfg(family, layers=2), qk_norm=False)
+    sd = synth.make_dit_state_dict(cfg, family, seed=61)
+    assert not any("norm_q" in k or "norm_k" in k for k in sd)
+    ref = build_reference(family, cfg, sd)                       # strict load: the reference has no such parameters either
+    inp = synth.make_dit_inputs(cfg, family, F, 10, 12, n_text=9, seed=62)
+    L = token_count(family, F, 10, 12, lfz, packed)
+    if family == "wan23" and packed:
+        t = torch.cat([torch.zeros(5), torch.full((L - 5,), 333.25)]).unsqueeze(0).double()
+    else:
+        t = torch.tensor([250.0])
+    want, _ = run_reference(ref, family, inp, t, L, lfz, packed)
+    got = run_oracle(dict(family=family, cfg=cfg, inputs=inp, t=t, seq_len=L, lfz=lfz, packed=packed), sd)
+    assert got.shape == want.shape
+    assert (got - want).abs().max().item() <= 2e-5
+    # and the switch changes the function (the same weights with the norms in place give another output)
+    cfg_n = dict(cfg, qk_norm=True)
+    sd_n = synth.make_dit_state_dict(cfg_n, family, seed=61)
+    other = run_oracle(dict(family=family, cfg=cfg_n, inputs=inp, t=t, seq_len=L, lfz=lfz, packed=packed), sd_n)
+    assert (other - got).abs().max().item() > 1e-3
+
+
 def _cache_case():
     from yume_amd import framepack
     family, F, H, W, lfz = "wan", 13, 10, 12, 9

@@ -239,8 +239,9 @@ __global__ __launch_bounds__(NT) void rmsnorm_rope_kernel(unsigned short* __rest
     const float s0 = block_sum(ss[0], red);
     float s1 = 0.f;
     if (nparts > 1) s1 = block_sum(ss[1], red);
-    const float r0 = rsqrtf(s0 / (float)C + eps);
-    const float r1 = rsqrtf(s1 / (float)C + eps);
+    // eps < 0: the rows are NOT normalised (the reference's nn.Identity in place of WanRMSNorm, qk_norm=False): y = x * w, then RoPE
+    const float r0 = eps < 0.f ? 1.f : rsqrtf(s0 / (float)C + eps);
+    const float r1 = eps < 0.f ? 1.f : rsqrtf(s1 / (float)C + eps);
     const float* rp = rope ? rope + t * 128 : nullptr;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
@@ -333,8 +334,8 @@ __global__ __launch_bounds__(NT) void rmsnorm_rope2_kernel(unsigned short* __res
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
         if (r == 1 && !two) break;
-        const float r0 = rsqrtf(ss[r][0] / (float)C + eps);
-        const float r1 = rsqrtf((nparts > 1 ? ss[r][1] : 0.f) / (float)C + eps);
+        const float r0 = eps < 0.f ? 1.f : rsqrtf(ss[r][0] / (float)C + eps);
+        const float r1 = eps < 0.f ? 1.f : rsqrtf((nparts > 1 ? ss[r][1] : 0.f) / (float)C + eps);
         const float* rp = rope ? rope + tr[r] * 128 : nullptr;
         unsigned short* row = buf + tr[r] * ld;
 #pragma unroll

@@ -124,14 +124,22 @@ class DiTEngine:
                         f32(pr[3].bias), f32(pr[4].weight), f32(pr[4].bias))
         blocks = []
         qs = math.log2(math.e) / math.sqrt(C // m.num_heads) if self.q_prescale else 1.0
+        # qk_norm=False (reference model.py:175-176): norm_q / norm_k are nn.Identity — the RoPE / scale kernel runs with its normalisation off
+        # (eps < 0, include/yume_hip.h) and a weight of ones (times the attention scale on the q side)
+        self.qk_eps = m.eps if getattr(m.blocks[0], "qk_norm", True) else -1.0
+
+        def nw(mod):
+            w = getattr(mod, "weight", None)
+            return (w if w is not None else torch.ones(C, device=dev)).double()
+
         for b in m.blocks:
             sa, ca = b.self_attn, b.cross_attn
             d = {
                 "wqkv": bf(torch.cat([sa.q.weight, sa.k.weight, sa.v.weight], dim=0)),
                 "bqkv": f32(torch.cat([sa.q.bias, sa.k.bias, sa.v.bias])),
-                "nqk": f32(torch.cat([sa.norm_q.weight.double() * qs, sa.norm_k.weight.double()])),
+                "nqk": f32(torch.cat([nw(sa.norm_q) * qs, nw(sa.norm_k)])),
                 "wo": bf(sa.o.weight), "bo": f32(sa.o.bias),
-                "wq_c": bf(ca.q.weight), "bq_c": f32(ca.q.bias), "nq_c": f32(ca.norm_q.weight.double() * qs),   # (cross q carries the scale too)
+                "wq_c": bf(ca.q.weight), "bq_c": f32(ca.q.bias), "nq_c": f32(nw(ca.norm_q) * qs),   # (cross q carries the scale too)
                 "wo_c": bf(ca.o.weight), "bo_c": f32(ca.o.bias),
                 "w1": bf(b.ffn[0].weight), "b1": f32(b.ffn[0].bias),
                 "w2": bf(b.ffn[2].weight), "b2": f32(b.ffn[2].bias),
@@ -146,11 +154,11 @@ class DiTEngine:
         cas = [b.cross_attn for b in m.blocks]
         P["wkv_c"] = bf(torch.cat([ca.k.weight for ca in cas] + [ca.v.weight for ca in cas], dim=0))
         P["bkv_c"] = f32(torch.cat([ca.k.bias for ca in cas] + [ca.v.bias for ca in cas]))
-        P["nk_c"] = f32(torch.stack([ca.norm_k.weight for ca in cas]))
+        P["nk_c"] = f32(torch.stack([nw(ca.norm_k) for ca in cas]))
         if self.family == "wan":
             P["wkv_i"] = bf(torch.cat([ca.k_img.weight for ca in cas] + [ca.v_img.weight for ca in cas], dim=0))
             P["bkv_i"] = f32(torch.cat([ca.k_img.bias for ca in cas] + [ca.v_img.bias for ca in cas]))
-            P["nk_i"] = f32(torch.stack([ca.norm_k_img.weight for ca in cas]))
+            P["nk_i"] = f32(torch.stack([nw(ca.norm_k_img) for ca in cas]))
         P["mod_all"] = f32(torch.cat([b.modulation.reshape(1, 6 * C) for b in m.blocks], dim=0))
         P["mod_head"] = f32(m.head.modulation.reshape(2, C))
         wh = m.head.head.weight.detach().float()
@@ -270,7 +278,7 @@ class DiTEngine:
         vct = self._buf(f"vct_{tag}_{nk}", (nb * C, nk64), torch.bfloat16, zero=True)
         if fresh:
             ops.gemm_bf16(ctx_rows, wkv, bkv, kc, EPI_BF16_SPLITT, out_t=vct, n_split=nb * C, variant=self.gemm_variant)
-            ops.rmsnorm_rows_periodic(kc.view(nk * nb, C), C, nk_w, self.model.eps)
+            ops.rmsnorm_rows_periodic(kc.view(nk * nb, C), C, nk_w, self.qk_eps)
         return kc, vct
 
     def _blocks(self, xs, L, tab, row_idx, R, rope, n_rope, ctx, n_img, ctx_fresh=True, n_keys=None, only=None, cache=None, n_trim=0):
@@ -317,12 +325,12 @@ class DiTEngine:
             T("adaln", ops.adaln_modulate, xs, scale_sa, shift_sa, ts, row_idx, True, h, 0, eps)
             T("gemm_qkv", ops.gemm_bf16, h, d["wqkv"], d["bqkv"], qk, EPI_BF16_SPLITT, out_t=vt, n_split=2 * C, variant=self.gemm_variant)
             if n_rope == L:
-                T("rmsnorm_rope", ops.rmsnorm_rope, qk, C, 2, d["nqk"], eps, rope)
+                T("rmsnorm_rope", ops.rmsnorm_rope, qk, C, 2, d["nqk"], self.qk_eps, rope)
             elif n_rope == 0:
-                ops.rmsnorm_rope(qk, C, 2, d["nqk"], eps, None)
+                ops.rmsnorm_rope(qk, C, 2, d["nqk"], self.qk_eps, None)
             else:
-                ops.rmsnorm_rope(qk[:n_rope], C, 2, d["nqk"], eps, rope)
-                ops.rmsnorm_rope(qk[n_rope:], C, 2, d["nqk"], eps, None)
+                ops.rmsnorm_rope(qk[:n_rope], C, 2, d["nqk"], self.qk_eps, rope)
+                ops.rmsnorm_rope(qk[n_rope:], C, 2, d["nqk"], self.qk_eps, None)
             if self.sp is None:
                 T("attn_self", ops.attn_fwd, qk[:, :C], qk[:, C:], vt, att, L, n_keys if n_keys is not None else L, H, variant=self.attn_variant,
                   q_prescaled=self.q_prescale, kv_padded=True)
@@ -339,7 +347,7 @@ class DiTEngine:
             else:
                 ops.cast_bf16(xs, L, h)
             T("gemm_cross_q", ops.gemm_bf16, h, d["wq_c"], d["bq_c"], qk[:, :C], EPI_BF16, variant=self.gemm_variant)
-            T("rmsnorm_rope", ops.rmsnorm_rope, qk[:, :C], C, 1, d["nq_c"], eps)
+            T("rmsnorm_rope", ops.rmsnorm_rope, qk[:, :C], C, 1, d["nq_c"], self.qk_eps)
             T("attn_cross", ops.attn_fwd, qk[:, :C], kc_t[:, i * C:(i + 1) * C], vct_t[i * C:(i + 1) * C], att, L, ntxt, H, variant=self.attn_variant,
               q_prescaled=self.q_prescale, kv_padded=True)
             if n_img:
@@ -366,7 +374,7 @@ class DiTEngine:
         n = L - s
         T("adaln", ops.adaln_modulate, xs, scale_sa, shift_sa, ts, row_idx, True, h, 0, eps)
         T("gemm_qkv", ops.gemm_bf16, h, d["wqkv"], d["bqkv"], qk, EPI_BF16_SPLITT, out_t=vt, n_split=2 * C, variant=self.gemm_variant)
-        T("rmsnorm_rope", ops.rmsnorm_rope, qk, C, 2, d["nqk"], eps, rope)
+        T("rmsnorm_rope", ops.rmsnorm_rope, qk, C, 2, d["nqk"], self.qk_eps, rope)
         T("attn_self", ops.attn_fwd, qo, qk[:, C:], vt, ao, n, L, H, variant=self.attn_variant, q_prescaled=self.q_prescale, kv_padded=True)
         T("gemm_o", ops.gemm_bf16, ao, d["wo"], d["bo"], xo, EPI_RESID, gate=gate_sa, gate_stride=ts, row_idx=ro, variant=self.gemm_variant)
         if "n3w" in d:
@@ -374,7 +382,7 @@ class DiTEngine:
         else:
             ops.cast_bf16(xo, n, ho)
         T("gemm_cross_q", ops.gemm_bf16, ho, d["wq_c"], d["bq_c"], qo, EPI_BF16, variant=self.gemm_variant)
-        T("rmsnorm_rope", ops.rmsnorm_rope, qo, C, 1, d["nq_c"], eps)
+        T("rmsnorm_rope", ops.rmsnorm_rope, qo, C, 1, d["nq_c"], self.qk_eps)
         T("attn_cross", ops.attn_fwd, qo, kc_t[:, i * C:(i + 1) * C], vct_t[i * C:(i + 1) * C], ao, n, ntxt, H, variant=self.attn_variant,
           q_prescaled=self.q_prescale, kv_padded=True)
         if img is not None:

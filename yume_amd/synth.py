@@ -70,13 +70,15 @@ def dit_param_shapes(cfg, family, pyramid=("_2x", "_4x", "_8x", "_16x", "_2x_f")
             for n in ("q", "k", "v", "o"):
                 sh[p + f"{att}.{n}.weight"] = (C, C)
                 sh[p + f"{att}.{n}.bias"] = (C,)
-            sh[p + f"{att}.norm_q.weight"] = (C,)
-            sh[p + f"{att}.norm_k.weight"] = (C,)
+            if cfg.get("qk_norm", True):       # (qk_norm=False: nn.Identity, no parameters — reference wan23/modules/model.py:175-176)
+                sh[p + f"{att}.norm_q.weight"] = (C,)
+                sh[p + f"{att}.norm_k.weight"] = (C,)
         if family == "wan":
             for n in ("k_img", "v_img"):
                 sh[p + f"cross_attn.{n}.weight"] = (C, C)
                 sh[p + f"cross_attn.{n}.bias"] = (C,)
-            sh[p + "cross_attn.norm_k_img.weight"] = (C,)
+            if cfg.get("qk_norm", True):
+                sh[p + "cross_attn.norm_k_img.weight"] = (C,)
         if cfg["cross_attn_norm"]:
             sh[p + "norm3.weight"] = (C,)
             sh[p + "norm3.bias"] = (C,)

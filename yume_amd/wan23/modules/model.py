@@ -40,17 +40,19 @@ class _Affine(nn.Module):
 
 
 class _Attention(nn.Module):
-    def __init__(self, dim, num_heads, eps, with_img=False):
+    def __init__(self, dim, num_heads, eps, with_img=False, qk_norm=True):
         super().__init__()
         self.dim, self.num_heads, self.head_dim, self.eps = dim, num_heads, dim // num_heads, eps
         for name in ("q", "k", "v", "o"):
             setattr(self, name, nn.Linear(dim, dim))
-        self.norm_q = _ScaleOnly(dim, eps)
-        self.norm_k = _ScaleOnly(dim, eps)
+        # reference model.py:175-176: `WanRMSNorm(dim, eps=eps) if qk_norm else nn.Identity()` — no parameters, q / k pass through
+        # (DiTEngine then runs the RoPE kernel with its normalisation switched off)
+        self.norm_q = _ScaleOnly(dim, eps) if qk_norm else nn.Identity()
+        self.norm_k = _ScaleOnly(dim, eps) if qk_norm else nn.Identity()
         if with_img:
             self.k_img = nn.Linear(dim, dim)
             self.v_img = nn.Linear(dim, dim)
-            self.norm_k_img = _ScaleOnly(dim, eps)
+            self.norm_k_img = _ScaleOnly(dim, eps) if qk_norm else nn.Identity()
 
 
 class WanAttentionBlock(nn.Module):
@@ -59,13 +61,11 @@ class WanAttentionBlock(nn.Module):
     def __init__(self, dim, ffn_dim, num_heads, window_size=(-1, -1), qk_norm=True, cross_attn_norm=False, eps=1e-6,
                  with_img=False):
         super().__init__()
-        if not qk_norm:
-            raise NotImplementedError("the Yume checkpoints use qk_norm=True; the HIP path fuses it")
         self.dim, self.ffn_dim, self.num_heads, self.eps = dim, ffn_dim, num_heads, eps
         self.window_size, self.qk_norm, self.cross_attn_norm = window_size, qk_norm, cross_attn_norm
-        self.self_attn = _Attention(dim, num_heads, eps)
+        self.self_attn = _Attention(dim, num_heads, eps, qk_norm=qk_norm)
         self.norm3 = _Affine(dim, eps) if cross_attn_norm else nn.Identity()
-        self.cross_attn = _Attention(dim, num_heads, eps, with_img=with_img)
+        self.cross_attn = _Attention(dim, num_heads, eps, with_img=with_img, qk_norm=qk_norm)
         self.ffn = nn.Sequential(nn.Linear(dim, ffn_dim), nn.GELU(approximate="tanh"), nn.Linear(ffn_dim, dim))
         self.modulation = nn.Parameter(torch.randn(1, 6, dim) / dim ** 0.5)
 
