@@ -362,6 +362,14 @@ __device__ __forceinline__ void fix7_v(const Dma7& d, const AttnArgs& p, int t, 
 #ifndef ATTN_ABLATE_VB
 #define ATTN_ABLATE_VB 0
 #endif
+// timing ablations of the steady tile's meeting point (WRONG results; profiles/r6_attention_steady_barrier_ablation.log): which of the
+// counted wait and the barrier the waves are parked at
+#ifndef ATTN_ABLATE_STEADY_BAR
+#define ATTN_ABLATE_STEADY_BAR 0
+#endif
+#ifndef ATTN_ABLATE_STEADY_WAIT
+#define ATTN_ABLATE_STEADY_WAIT 0
+#endif
 #ifndef ATTN_ABLATE_KC
 #define ATTN_ABLATE_KC 0
 #endif
@@ -505,8 +513,12 @@ template <int TS, bool FAST>
 __device__ __forceinline__ void steady7(const Ctx& cx, const Dma7& dp, const char*& kg, const char*& vg, int64_t kstep, Blk& A, Blk& B, u32x4 (&ring)[RD]) {
     constexpr int vb = TS * SLOT, nkb = ((TS + 2) & 3) * SLOT;      // V^T(t); K(t+2) for the cache refill (K(t+1) is in the cache)
     constexpr int dk = TS * SLOT, dv = VB + ((TS + 3) & 3) * SLOT;      // K(t+4) takes K(t)'s slot, V^T(t+3) the slot V^T(t-1) left
+#if !ATTN_ABLATE_STEADY_WAIT
     asm volatile("s_waitcnt vmcnt(8)" ::: "memory");      // everything older than the previous tile's 8 pieces has landed
+#endif
+#if !ATTN_ABLATE_STEADY_BAR
     __builtin_amdgcn_s_barrier();
+#endif
     phase<FAST, OA, QA, OB, true, true, true, false, true, false, true, -1, dk, dv>(cx, A, B, ring, vb, 0, 0, dp, kg, vg);
     phase<FAST, OB, QB, OA, true, true, true, false, true, false, false, nkb>(cx, B, A, ring, vb, 0, 0, dp, kg, vg);
     kg += kstep;
