@@ -292,9 +292,15 @@ int yume_transpose_bf16(const void* in, int in_bf16, int64_t ldi, int64_t rows, 
  *   gathering A loader. YUME_CONV_KORDER=0/1/2 selects the K walk of that loader (default 2: dt, channel tile, dh, dw).
  * epi: YUME_EPI_BF16 (bias), YUME_EPI_F32, YUME_CONV_EPI_ADD (out = acc + bias + add[m, co], add bf16 [M, ldadd] —
  *      the ResidualBlock skip, vae2_2.py:239), YUME_CONV_EPI_TSPLIT (upsample3d time_conv, vae2_2.py:145-153:
- *      channel halves of frame t become frames 2t and 2t+1: out[((2t+j)*Ho*Wo + hw), c] for co = j*Cout/2 + c).
+ *      channel halves of frame t become frames 2t and 2t+1: out[((2t+j)*Ho*Wo + hw), c] for co = j*Cout/2 + c),
+ *      YUME_CONV_EPI_RMS_SILU (r6): out = SiLU(RMS_norm(acc + bias) * gamma) — the ResidualBlock's second RMS_norm + SiLU behind its first
+ *      convolution (wan/modules/vae.py:75-84 RMS_norm = F.normalize over the channels * sqrt(C) * gamma; :190-207 ResidualBlock; vae2_2.py likewise);
+ *      `add` then carries the fp32 gamma[Cout] (ldadd ignored). Fused into the epilogue where one workgroup holds a position's whole channel
+ *      row (csrc/conv_halo_n.hpp: Cout 96 / 160; the norm sees the fp32 accumulators); on every other kernel choice the call is the plain
+ *      convolution followed by yume_vae_rmsnorm_silu in place (the norm sees the bf16 image): the same function to bf16 rounding.
+ *      YUME_CONV_FUSE_NORM=0 forces the second form.
  */
-enum { YUME_CONV_EPI_ADD = 16, YUME_CONV_EPI_TSPLIT = 17 };
+enum { YUME_CONV_EPI_ADD = 16, YUME_CONV_EPI_TSPLIT = 17, YUME_CONV_EPI_RMS_SILU = 18 };
 int yume_conv3d_cl(const void* x, const void* cache, int64_t ldc, int64_t Tin, int64_t Hin, int64_t Win, int64_t Cin,
                    const void* W, int64_t ldw, const float* bias, int64_t Cout,
                    int kt, int kh, int kw, int st, int sh, int sw, int pt, int ph, int pw, int ups,

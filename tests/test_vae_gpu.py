@@ -504,6 +504,35 @@ def test_conv_halo_n_96_and_160_channel_levels_vs_torch(C, T, H, W, with_cache):
     assert torch.equal(out, out2)
 
 
+@pytest.mark.parametrize("Cin,Cout,T,H,W", [(96, 96, 2, 130, 150), (160, 160, 1, 128, 132), (96, 192, 1, 128, 130), (64, 64, 2, 20, 24), (192, 192, 1, 64, 64)])
+def test_conv_with_rms_norm_and_silu_behind_it(Cin, Cout, T, H, W):
+    """YUME_CONV_EPI_RMS_SILU (r6): the ResidualBlock's second RMS_norm + SiLU (wan/modules/vae.py:75-84, :190-207) inside the first convolution's
+    call — fused into conv_halo_n's epilogue at 96 / 160 output channels (the first two cases; the norm sees the fp32 accumulators), the plain
+    convolution + the norm kernel in place on every other kernel choice (two launches of conv_halo_n, the GEMM kernels, conv_w4)."""
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    x = rnd(Cin, T, H, W, seed=71).bfloat16().float()
+    cache = rnd(Cin, 2, H, W, seed=72).bfloat16().float()
+    w = (rnd(Cout, Cin, 3, 3, 3, seed=73) * (27 * Cin) ** -0.5).bfloat16().float()
+    b = rnd(Cout, seed=74) * 0.1
+    g = 1 + 0.1 * rnd(Cout, seed=75)
+    y = F.conv3d(F.pad(torch.cat([cache, x], dim=1).unsqueeze(0), (1, 1, 1, 1)), w, b)[0]
+    want = F.silu(F.normalize(y, dim=0) * Cout ** 0.5 * g.view(-1, 1, 1, 1))
+    out = torch.full((T, H, W, Cout), 7.0, dtype=torch.bfloat16, device=DEV)
+    V.conv3d_cl(cl(x), cl(cache), pack_w(w), b.to(DEV), Cout, (3, 3, 3), (1, 1, 1), (2, 1, 1), False, out, V.EPI_RMS_SILU, add=g.to(DEV),
+                zero_page=zero_page())
+    got = ncthw(out)
+    assert torch.isfinite(got).all()
+    assert rel_l2(got, want) < 6e-3, rel_l2(got, want)
+    assert (got - want).abs().max() <= 2.0 ** -5 * want.abs().max() + 1e-3
+    for sl in ((slice(None), 0), (slice(None), slice(None), 0), (slice(None), slice(None), -1), (slice(None), slice(None), slice(None), 0),
+               (slice(None), slice(None), slice(None), -1)):
+        assert rel_l2(got[sl], want[sl]) < 6e-3, sl
+    out2 = torch.empty_like(out)
+    V.conv3d_cl(cl(x), cl(cache), pack_w(w), b.to(DEV), Cout, (3, 3, 3), (1, 1, 1), (2, 1, 1), False, out2, V.EPI_RMS_SILU, add=g.to(DEV),
+                zero_page=zero_page())
+    assert torch.equal(out, out2)
+
+
 @pytest.mark.parametrize("with_cache,H,W", [(True, 136, 128), (False, 130, 150)])
 def test_conv_halo_n_head_96_to_4_channels_vs_torch(with_cache, H, W):
     """the Wan2.1 decoder's head (wan/modules/vae.py:466-468: RMS_norm, SiLU, CausalConv3d(96, 3, 3, padding=1)) — 4 (3 + pad) output channels in

@@ -56,9 +56,10 @@ def _frames(got, want):
     return [(d[:, t].norm() / want[:, t].double().norm().clamp_min(1e-30)).item() for t in range(want.shape[1])]
 
 
-@pytest.mark.parametrize("version,zshape", [("2.2", (48, 1, 44, 80)), ("2.1", (16, 1, 68, 120))])
+@pytest.mark.parametrize("version,zshape", [("2.2", (48, 1, 44, 40)), ("2.1", (16, 1, 68, 120))])
 def test_device_gold_reproduces_the_cpu_oracle_first_latent_decode(version, zshape):
-    """the proof of the device gold for each decoder: full resolution, one latent (the CPU oracle's affordable size)."""
+    """the proof of the device gold for each decoder: one latent at production height (Wan2.2: 704 x 640 frames — half the width of r5's case, which
+    took 64 s of CPU oracle time in a suite that has to stay under 700 s; the whole-chunk tests below run the full 704 x 1280 against the gold)."""
     cfg, sd, vae = _vae(version, 31)
     z = torch.randn(*zshape, generator=torch.Generator().manual_seed(32))
     torch.set_num_threads(min(32, torch.get_num_threads()))
@@ -80,9 +81,9 @@ def test_device_gold_reproduces_the_cpu_oracle_first_latent_decode(version, zsha
 
 
 def test_device_gold_reproduces_the_cpu_oracle_five_frame_encode():
-    """... and for the encoder path (first frame + one cached 4-frame chunk: strided temporal convs, AvgDown3D) at 704 x 640."""
+    """... and for the encoder path (first frame + one cached 4-frame chunk: strided temporal convs, AvgDown3D) at 352 x 640."""
     cfg, sd, _ = _vae("2.2", 33)
-    video = torch.rand(3, 5, 704, 640, generator=torch.Generator().manual_seed(34)) * 2 - 1
+    video = torch.rand(3, 5, 352, 640, generator=torch.Generator().manual_seed(34)) * 2 - 1
     torch.set_num_threads(min(32, torch.get_num_threads()))
     t0 = time.time()
     want = ovae.encode(sd, cfg, video)

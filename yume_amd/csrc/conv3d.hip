@@ -206,6 +206,18 @@ extern "C" int yume_conv3d_cl(const void* x, const void* cache, int64_t ldc, int
                               const void* zero_page, void* stream) {
     const int variant = 0;
     YUME_REQUIRE(x && W && out && zero_page, "conv3d_cl: NULL pointer");
+    if (epi == YUME_CONV_EPI_RMS_SILU) {
+        // out = SiLU(RMS_norm(conv + bias) * gamma), `add` = the fp32 gamma[Cout]: fused into the epilogue where one workgroup holds a position's
+        // whole channel row (conv_halo_n.hpp, 96 / 160 output channels); elsewhere the plain convolution and the norm kernel in place behind it
+        YUME_REQUIRE(add != nullptr, "conv3d_cl: the RMS_SILU epilogue needs gamma in `add`");
+        static const bool fuse = [] { const char* v = getenv("YUME_CONV_FUSE_NORM"); return !v || atoi(v) != 0; }();
+        if (!fuse || !conv_halo_n::applies(Cin, Cout, kt, kh, kw, st, sh, sw, pt, ph, pw, ups, Hin, Win, Ho, Wo, ldc, ldo, ldw, epi, 0)) {
+            int rc = yume_conv3d_cl(x, cache, ldc, Tin, Hin, Win, Cin, W, ldw, bias, Cout, kt, kh, kw, st, sh, sw, pt, ph, pw, ups, To, Ho, Wo,
+                                    YUME_EPI_BF16, out, ldo, nullptr, 0, zero_page, stream);
+            if (rc != YUME_OK) return rc;
+            return yume_vae_rmsnorm_silu(out, ldo, To * Ho * Wo, Cout, (const float*)add, nullptr, 1, out, ldo, stream);
+        }
+    }
     YUME_REQUIRE(Tin > 0 && Hin > 0 && Win > 0 && Cin > 0 && Cout > 0 && To > 0 && Ho > 0 && Wo > 0, "conv3d_cl: empty shape");
     YUME_REQUIRE((Cin % 8) == 0 && (ldc % 8) == 0 && ldc >= Cin, "conv3d_cl: Cin=%lld and ldc=%lld must be multiples of 8", (long long)Cin, (long long)ldc);
     YUME_REQUIRE((Cout % 4) == 0 && (ldo % 4) == 0, "conv3d_cl: Cout and ldo must be multiples of 4");
@@ -260,12 +272,13 @@ extern "C" int yume_conv3d_cl(const void* x, const void* cache, int64_t ldc, int
         YUME_REQUIRE(epi != YUME_CONV_EPI_ADD || add != nullptr, "conv3d_cl: ADD epilogue needs an addend");
         conv_halo_n::Params hp;
         hp.x = al.x; hp.cache = al.cache; hp.w = (const unsigned short*)W; hp.bias = bias; hp.out = (unsigned short*)out;
-        hp.add = (const unsigned short*)add;
+        hp.add = epi == YUME_CONV_EPI_RMS_SILU ? nullptr : (const unsigned short*)add;
+        hp.gamma = epi == YUME_CONV_EPI_RMS_SILU ? (const float*)add : nullptr;
         hp.ldc = ldc; hp.ldw = ldw; hp.ldo = ldo; hp.ldadd = ldadd;
         hp.Tin = (int)Tin; hp.H = (int)Hin; hp.W = (int)Win; hp.C = (int)Cin; hp.To = (int)To; hp.cout = (int)Cout; hp.kt = kt; hp.pt = pt;
         static const bool log_on = [] { const char* v = getenv("YUME_CONV_LOG"); return v && atoi(v) != 0; }();
         if (log_on) fprintf(stderr, "[conv3d_cl] halo_n M=%lld Cin=%lld Cout=%lld k=%dx%dx%d\n", (long long)M, (long long)Cin, (long long)Cout, kt, kh, kw);
-        const bool addep = epi == YUME_CONV_EPI_ADD;
+        const int addep = epi == YUME_CONV_EPI_ADD ? 1 : epi == YUME_CONV_EPI_RMS_SILU ? 2 : 0;
         // 96 channels: two waves per SIMD (8 waves x 4 m-tiles of one workgroup; measured 3-5 % ahead of 4 waves x 8 m-tiles in the first build,
         // whose unrolled tap loop no longer fits the register file without scratch traffic: not instantiated); 160 channels / the 16-channel head:
         // one wave per SIMD (profiles/r6_conv_halo_n_ablations.log)
@@ -284,7 +297,7 @@ extern "C" int yume_conv3d_cl(const void* x, const void* cache, int64_t ldc, int
                 q.cout = inst;
             }
             if (ups)
-                rc = addep ? -2 : conv_halo_n::launch_inst<6, 4, 8, 64, 8, true>(q, To, Ho, Wo, false, s);
+                rc = addep ? -2 : conv_halo_n::launch_inst<6, 4, 8, 64, 8, true>(q, To, Ho, Wo, 0, s);
             else if (inst == 16)
                 rc = conv_halo_n::launch_inst<1, 8, 8, 64, 4>(q, To, Ho, Wo, addep, s);
             else if (inst == 96)

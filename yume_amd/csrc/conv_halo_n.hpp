@@ -35,6 +35,7 @@ struct Params {
     const float* bias;             // [cout] or nullptr
     unsigned short* out;           // [To, H, W, ldo]
     const unsigned short* add;     // EPI ADD: [To, H, W, ldadd] or nullptr
+    const float* gamma;            // EPI RMS_SILU: [cout] — out = SiLU(RMS_norm(acc + bias) * gamma), the norm over the cout channels of a position
     int64_t ldc, ldw, ldo, ldadd;
     int Tin, H, W, C, To, cout, kt, pt;      // H, W: the INPUT frame (the output frame is 2H x 2W with the folded nearest-2x upsample)
     int tiles_w, tiles_h;
@@ -90,7 +91,8 @@ struct Geo {
 // (r6, third build) The tap loop is a RUN-TIME loop: the first two builds unrolled the 9 taps of a step (compile-time wait counts) and the
 // compiler, pipelining across them, ran out of registers (44-110 VGPRs to scratch in the persistent form — and scratch traffic counts in vmcnt,
 // which the counted waits below cannot tolerate). With uniform issue counts per tap one wait immediate serves every tap.
-template <int NJ, int MI, int TH, int TW, int NW, bool ADD, bool UPS = false>
+// EPI: 0 bias only, 1 + the shortcut (ADD), 2 RMS_norm over the output channels + SiLU (the residual block's second norm, fused: r6)
+template <int NJ, int MI, int TH, int TW, int NW, int EPI, bool UPS = false>
 __global__ __launch_bounds__(NW * 64, NW / 4) void conv_halo_n_kernel(Params p) {
     using G = Geo<NJ, MI, TH, TW, NW, UPS>;
     __shared__ __attribute__((aligned(16))) char smem[G::LDS];
@@ -251,6 +253,40 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void conv_halo_n_kernel(Params p) 
             if (ho >= OH || wo >= OW) continue;
             const int64_t pos = ((int64_t)to * OH + ho) * OW + wo;
             unsigned short* o = p.out + pos * p.ldo + nch;
+            if constexpr (EPI == 2) {
+                // The position's NJ * 16 channels sit in this lane (4 per n-tile) and in the three lanes 16, 32, 48 further on: RMS_norm of
+                // vae.py's RMS_norm (F.normalize over the channels * sqrt(C) * gamma, eps 1e-12 on the norm) on the fp32 accumulators, then SiLU
+                // — what the stand-alone kernel (vae_ops.hip) does to the bf16 image of the same values one launch later.
+                // (two passes over the accumulators instead of a copy of the row: the 96-channel instance has 256 registers per lane)
+                float ss = 0.f;
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    f32x4 v = acc[i][j];
+                    if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + 16 * j + nch);
+                    ss += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+                }
+                ss += __shfl_xor(ss, 16, 64);
+                ss += __shfl_xor(ss, 32, 64);
+                const float inv = sqrtf((float)(NJ * 16)) / fmaxf(sqrtf(ss), 1e-12f);
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    f32x4 v = acc[i][j];
+                    if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + 16 * j + nch);
+                    const f32x4 g = *reinterpret_cast<const f32x4*>(p.gamma + 16 * j + nch);
+                    float r[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const float t = v[k] * inv * g[k];
+                        r[k] = t * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * t));
+                    }
+                    u32x2 ov;
+                    ov[0] = pack_bf16x2(r[0], r[1]);
+                    ov[1] = pack_bf16x2(r[2], r[3]);
+                    *reinterpret_cast<u32x2*>(o + 16 * j) = ov;
+                }
+                continue;
+            }
+            constexpr bool ADD = EPI == 1;
             const unsigned short* a = ADD ? p.add + pos * p.ldadd + nch : nullptr;
             u32x2 a2[NJ];
             if (ADD) {
@@ -298,7 +334,8 @@ inline bool applies(int64_t Cin, int64_t Cout, int kt, int kh, int kw, int st, i
     static const bool on = [] { const char* v = getenv("YUME_CONV_HALO_N"); return !v || atoi(v) != 0; }();
     if (!on || st != 1 || sh != 1 || sw != 1 || kh != 3 || kw != 3 || ph != 1 || pw != 1) return false;
     if (!((kt == 3 && pt == 2) || (kt == 1 && pt == 0))) return false;
-    if (epi != YUME_EPI_BF16 && epi != YUME_CONV_EPI_ADD) return false;
+    if (epi != YUME_EPI_BF16 && epi != YUME_CONV_EPI_ADD && epi != YUME_CONV_EPI_RMS_SILU) return false;
+    if (epi == YUME_CONV_EPI_RMS_SILU && (ups || (Cout != 96 && Cout != 160))) return false;      // the whole channel row in one workgroup
     if (instance(Cin, Cout, ups) == 0) return false;
     if (ups ? (Ho != 2 * Hin || Wo != 2 * Win || kt != 1) : (Ho != Hin || Wo != Win)) return false;
     if ((ldc % 8) != 0 || (ldw % 8) != 0 || (ldo % 4) != 0 || ldo < Cout || (Cout % 4) != 0 || (epi == YUME_CONV_EPI_ADD && ((ldadd % 4) != 0 || ldadd < Cout))) return false;
@@ -307,7 +344,7 @@ inline bool applies(int64_t Cin, int64_t Cout, int kt, int kh, int kw, int st, i
 }
 
 template <int NJ, int MI, int TH, int TW, int NW, bool UPS = false>
-inline int launch_inst(Params hp, int64_t To, int64_t Ho, int64_t Wo, bool add, hipStream_t s) {
+inline int launch_inst(Params hp, int64_t To, int64_t Ho, int64_t Wo, int epi_kind, hipStream_t s) {
     hp.tiles_w = (int)((Wo + TW - 1) / TW);
     hp.tiles_h = (int)((Ho + TH - 1) / TH);
     const int64_t nt = To * hp.tiles_h * hp.tiles_w;
@@ -322,8 +359,15 @@ inline int launch_inst(Params hp, int64_t To, int64_t Ho, int64_t Wo, bool add, 
     }();
     const int64_t per_xcd = persist ? (ncu + 7) / 8 : (nt + 7) / 8;
     const unsigned grid = (unsigned)(8 * ((nt + 7) / 8 < per_xcd ? (nt + 7) / 8 : per_xcd));
-    if (add) hipLaunchKernelGGL((conv_halo_n_kernel<NJ, MI, TH, TW, NW, true, UPS>), dim3(grid), dim3(NW * 64), 0, s, hp);
-    else hipLaunchKernelGGL((conv_halo_n_kernel<NJ, MI, TH, TW, NW, false, UPS>), dim3(grid), dim3(NW * 64), 0, s, hp);
+    if constexpr (!UPS && NJ > 1) {
+        if (epi_kind == 2) {
+            hipLaunchKernelGGL((conv_halo_n_kernel<NJ, MI, TH, TW, NW, 2, UPS>), dim3(grid), dim3(NW * 64), 0, s, hp);
+            return 0;
+        }
+    }
+    if (epi_kind == 2) return -3;
+    if (epi_kind == 1) hipLaunchKernelGGL((conv_halo_n_kernel<NJ, MI, TH, TW, NW, 1, UPS>), dim3(grid), dim3(NW * 64), 0, s, hp);
+    else hipLaunchKernelGGL((conv_halo_n_kernel<NJ, MI, TH, TW, NW, 0, UPS>), dim3(grid), dim3(NW * 64), 0, s, hp);
     return 0;
 }
 

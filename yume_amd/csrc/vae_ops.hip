@@ -8,10 +8,10 @@ namespace {
 
 // ---- RMS_norm (+SiLU): LPR lanes cooperate on one row, 64/LPR rows per wave, 4 waves per workgroup ----
 template <int LPR, int NV>
-__global__ __launch_bounds__(256) void rmsnorm_silu_kernel(const unsigned short* __restrict__ x, int64_t ldx, int64_t M,
+__global__ __launch_bounds__(256) void rmsnorm_silu_kernel(const unsigned short* x, int64_t ldx, int64_t M,
                                                            int C, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, int silu_on,
-                                                           unsigned short* __restrict__ y, int64_t ldy) {
+                                                           unsigned short* y, int64_t ldy) {      // (x == y allowed: a row is read whole before it is written)
     constexpr int RPW = 64 / LPR;
     const int lane = threadIdx.x & 63;
     const int sub = lane % LPR;
@@ -80,9 +80,9 @@ __device__ __forceinline__ f32x2_t silu2_fast(f32x2_t x) {
 }
 
 template <int G, int NVL, int RI>
-__global__ __launch_bounds__(256) void rmsnorm_silu_g_kernel(const unsigned short* __restrict__ x, int64_t ldx, int64_t M, int C,
+__global__ __launch_bounds__(256) void rmsnorm_silu_g_kernel(const unsigned short* x, int64_t ldx, int64_t M, int C,
                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                             int silu_on, unsigned short* __restrict__ y, int64_t ldy) {
+                                                             int silu_on, unsigned short* y, int64_t ldy) {      // (x == y allowed)
     constexpr int RPW = 64 / G;
     const int lane = threadIdx.x & 63;
     const int sub = lane % G;
@@ -154,8 +154,8 @@ __global__ __launch_bounds__(256) void rmsnorm_silu_g_kernel(const unsigned shor
 // leaves the row's scale, every lane picks up the scale of the row of each of its vectors. gamma (and beta) belong to (lane, i) alone
 // (a chunk starts on a row boundary), so they stay in registers across the RI chunks of a wave.
 template <int NVEC, int NVL, int RI, bool SILU, bool BETA>
-__global__ __launch_bounds__(256) void rmsnorm_silu_flat_kernel(const unsigned short* __restrict__ x, int64_t M, const float* __restrict__ gamma,
-                                                                const float* __restrict__ beta, unsigned short* __restrict__ y) {
+__global__ __launch_bounds__(256) void rmsnorm_silu_flat_kernel(const unsigned short* x, int64_t M, const float* __restrict__ gamma,
+                                                                const float* __restrict__ beta, unsigned short* y) {      // (x == y allowed: a wave reads its chunk whole before it writes)
     constexpr int CH = NVL * 64;                 // vectors per chunk
     constexpr int R = CH / NVEC;                 // rows per chunk
     static_assert(R * NVEC == CH && R <= 64 && (NVEC % 4) == 0, "a chunk is whole rows");

@@ -127,16 +127,23 @@ class VaeEngine:
         c[1].copy_(x[0])
         cache[name] = c
 
-    def _conv3(self, name, x, cache, add=None):
-        """CausalConv3d with a temporal kernel (3x3x3 or (3,1,1)), stride 1: reads cache[name], then updates it."""
+    def _conv3(self, name, x, cache, add=None, norm=None):
+        """CausalConv3d with a temporal kernel (3x3x3 or (3,1,1)), stride 1: reads cache[name], then updates it.
+        norm: the name of an RMS_norm (+ SiLU) applied to the convolution's output inside the same C-ABI call (YUME_CONV_EPI_RMS_SILU)."""
         p = self.P[name]
         kt, kh, kw = p["k"]
         T, H, W, C = x.shape
         out = self._new(T, H, W, _ru(p["co"], 8))
         if out.shape[3] != p["cop"]:
             out.zero_()
+        if norm is not None:
+            if add is not None or out.shape[3] != p["cop"] or p["cop"] != p["co"]:
+                raise RuntimeError("yume_amd.vae: the fused norm needs an unpadded channel row and no shortcut")
+            epi, operand = V.EPI_RMS_SILU, self.P[norm + ".gamma"]
+        else:
+            epi, operand = (V.EPI_ADD if add is not None else V.EPI_BF16), add
         V.conv3d_cl(x, cache.get(name), p["w"], p["b"], p["cop"], (kt, kh, kw), (1, 1, 1), (kt - 1, kh // 2, kw // 2), False,
-                    out, V.EPI_ADD if add is not None else V.EPI_BF16, add=add, zero_page=self.zero)
+                    out, epi, add=operand, zero_page=self.zero)
         self._update_cache(cache, name, x)
         return out
 
@@ -157,8 +164,10 @@ class VaeEngine:
 
     def _res(self, name, x, cache):
         h = self._conv1(name + ".shortcut", x) if (name + ".shortcut") in self.P else x
-        y = self._conv3(name + ".residual.2", self._norm(name + ".residual.0", x), cache)
-        return self._conv3(name + ".residual.6", self._norm(name + ".residual.3", y), cache, add=h)
+        # residual.3 (RMS_norm) + residual.4 (SiLU) ride in the epilogue of residual.2's call: conv -> norm -> SiLU is one C-ABI call
+        # (fused in the kernel at the 96 / 160-channel levels, conv + in-place norm kernel elsewhere; include/yume_hip.h)
+        yn = self._conv3(name + ".residual.2", self._norm(name + ".residual.0", x), cache, norm=name + ".residual.3")
+        return self._conv3(name + ".residual.6", yn, cache, add=h)
 
     def _attn(self, name, x):
         """AttentionBlock: per frame, one head of width C over the H*W positions (two GEMMs + a row softmax)."""

@@ -5,7 +5,7 @@ import torch
 from . import _lib
 from .ops import _dev, _ptr, _stream, ensure_counters
 
-EPI_BF16, EPI_F32, EPI_ADD, EPI_TSPLIT = 0, 2, 16, 17
+EPI_BF16, EPI_F32, EPI_ADD, EPI_TSPLIT, EPI_RMS_SILU = 0, 2, 16, 17, 18
 
 
 def _cl(t, name):
@@ -29,12 +29,19 @@ def conv3d_cl(x, cache, w, bias, cout, k, stride, pad, ups, out, epi=EPI_BF16, a
         _cl(cache, "cache")
         if tuple(cache.shape) != (2, Hin, Win, C):
             raise RuntimeError("yume_amd.vae: cache must be [2,Hin,Win,C]")
-    if add is not None:
+    ldadd = 0
+    if epi == EPI_RMS_SILU:
+        # `add` carries the fp32 gamma of the RMS_norm fused behind the convolution (include/yume_hip.h)
+        _dev(add, "gamma", torch.float32)
+        if add.numel() < cout or not add.is_contiguous():
+            raise RuntimeError("yume_amd.vae: gamma must be a contiguous fp32 vector of >= cout elements")
+    elif add is not None:
         _cl(add, "add")
+        ldadd = add.shape[3]
     rc = lib.yume_conv3d_cl(x.data_ptr(), _ptr(cache), C, Tin, Hin, Win, cin if cin is not None else C, w.data_ptr(),
                             w.shape[1], _ptr(bias), cout, k[0], k[1], k[2], stride[0], stride[1], stride[2], pad[0],
                             pad[1], pad[2], 1 if ups else 0, To, Ho, Wo, epi, out.data_ptr(), Cl,
-                            _ptr(add), add.shape[3] if add is not None else 0, zero_page.data_ptr(), _stream())
+                            _ptr(add), ldadd, zero_page.data_ptr(), _stream())
     _lib.check(rc, "yume_conv3d_cl")
     return out
 
