@@ -152,11 +152,20 @@ __global__ __launch_bounds__(NT) void adaln2_kernel(const float* __restrict__ x,
                 v[r][i] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
         }
+    // (the two rows of a block nearly always carry the same modulation row — the rows of a timestep are contiguous tokens —: one set of loads then)
+    const int64_t mrow[2] = {row_idx ? (int64_t)row_idx[tr[0]] : 0, row_idx ? (int64_t)row_idx[tr[1]] : 0};
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
-        const int64_t row = row_idx ? (int64_t)row_idx[tr[r]] : 0;
-        const float* mr = mul + row * tab_stride;
-        const float* ar = add + row * tab_stride;
+        if (r == 1 && mrow[1] == mrow[0]) {
+#pragma unroll
+            for (int i = 0; i < MAXV; ++i) {
+                m4v[1][i] = m4v[0][i];
+                a4v[1][i] = a4v[0][i];
+            }
+            break;
+        }
+        const float* mr = mul + mrow[r] * tab_stride;
+        const float* ar = add + mrow[r] * tab_stride;
 #pragma unroll
         for (int i = 0; i < MAXV; ++i) {
             const int vi = threadIdx.x + i * NT;
@@ -331,45 +340,54 @@ __global__ __launch_bounds__(NT) void rmsnorm_rope2_kernel(unsigned short* __res
         }
         ss[0][0] = p[0]; ss[0][1] = p[1]; ss[1][0] = p[2]; ss[1][1] = p[3];
     }
+    // The auxiliary loads are hoisted (r6, second half): a thread's NV vectors of a row all sit at the same offset inside their head
+    // ((8 * NT) % 128 == 0), so its RoPE pairs are ONE 32-byte read per row, not one per vector; the weights of vector i serve both rows.
+    // As written before (4 auxiliary 16-byte loads per 16-byte vector of data) the kernel moved five times its data through the CU's
+    // texture path. Same arithmetic in the same order: same bits.
+    static_assert((8 * NT) % 128 == 0, "a thread's vectors share their offset inside the head");
+    float rs[2][2];
+    f32x4 cs0[2], cs1[2];
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
-        if (r == 1 && !two) break;
-        const float r0 = eps < 0.f ? 1.f : rsqrtf(ss[r][0] / (float)C + eps);
-        const float r1 = eps < 0.f ? 1.f : rsqrtf((nparts > 1 ? ss[r][1] : 0.f) / (float)C + eps);
-        const float* rp = rope ? rope + tr[r] * 128 : nullptr;
-        unsigned short* row = buf + tr[r] * ld;
+        rs[r][0] = eps < 0.f ? 1.f : rsqrtf(ss[r][0] / (float)C + eps);
+        rs[r][1] = eps < 0.f ? 1.f : rsqrtf((nparts > 1 ? ss[r][1] : 0.f) / (float)C + eps);
+        if (rope) {
+            const float* rp = rope + tr[r] * 128 + 2 * (((8 * threadIdx.x) & 127) >> 1);
+            cs0[r] = *reinterpret_cast<const f32x4*>(rp);
+            cs1[r] = *reinterpret_cast<const f32x4*>(rp + 4);
+        }
+    }
 #pragma unroll
-        for (int i = 0; i < NV; ++i) {
-            const int vi = threadIdx.x + i * NT;
-            if (vi < nvec) {
-                const float rr = vi >= vpp ? r1 : r0;
-                const int c0 = 8 * vi;
-                const f32x4 w0 = *reinterpret_cast<const f32x4*>(w + c0);
-                const f32x4 w1 = *reinterpret_cast<const f32x4*>(w + c0 + 4);
-                float y[8];
+    for (int i = 0; i < NV; ++i) {
+        const int vi = threadIdx.x + i * NT;
+        if (vi >= nvec) continue;
+        const int c0 = 8 * vi;
+        const f32x4 w0 = *reinterpret_cast<const f32x4*>(w + c0);
+        const f32x4 w1 = *reinterpret_cast<const f32x4*>(w + c0 + 4);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    y[j] = bf16_to_f32(v[r][i][j]) * rr * w0[j];
-                    y[4 + j] = bf16_to_f32(v[r][i][4 + j]) * rr * w1[j];
-                }
-                if (rp) {
-                    const int pr = (c0 & 127) >> 1;
-                    const f32x4 cs0 = *reinterpret_cast<const f32x4*>(rp + 2 * pr);
-                    const f32x4 cs1 = *reinterpret_cast<const f32x4*>(rp + 2 * pr + 4);
-                    const float cs[8] = {cs0[0], cs0[1], cs0[2], cs0[3], cs1[0], cs1[1], cs1[2], cs1[3]};
+        for (int r = 0; r < 2; ++r) {
+            if (r == 1 && !two) break;
+            const float rr = vi >= vpp ? rs[r][1] : rs[r][0];
+            float y[8];
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const float a = y[2 * q], b = y[2 * q + 1];
-                        const float c = cs[2 * q], sn = cs[2 * q + 1];
-                        y[2 * q] = a * c - b * sn;
-                        y[2 * q + 1] = a * sn + b * c;
-                    }
-                }
-                u32x4 o;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) o[j] = pack_bf16x2(y[2 * j], y[2 * j + 1]);
-                *reinterpret_cast<u32x4*>(row + 8 * vi) = o;
+            for (int j = 0; j < 4; ++j) {
+                y[j] = bf16_to_f32(v[r][i][j]) * rr * w0[j];
+                y[4 + j] = bf16_to_f32(v[r][i][4 + j]) * rr * w1[j];
             }
+            if (rope) {
+                const float cs[8] = {cs0[r][0], cs0[r][1], cs0[r][2], cs0[r][3], cs1[r][0], cs1[r][1], cs1[r][2], cs1[r][3]};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float a = y[2 * q], b = y[2 * q + 1];
+                    const float c = cs[2 * q], sn = cs[2 * q + 1];
+                    y[2 * q] = a * c - b * sn;
+                    y[2 * q + 1] = a * sn + b * c;
+                }
+            }
+            u32x4 o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = pack_bf16x2(y[2 * j], y[2 * j + 1]);
+            *reinterpret_cast<u32x4*>(buf + tr[r] * ld + 8 * vi) = o;
         }
     }
 }
