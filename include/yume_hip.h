@@ -312,6 +312,8 @@ int yume_conv3d_cl(const void* x, const void* cache, int64_t ldc, int64_t Tin, i
  *           in ResidualBlock (:204-208) and the heads (:560-561,676-677).
  *   y[m, c] = act( x[m, c] / max(||x[m, :]||_2, 1e-12) * sqrt(C) * gamma[c] + beta[c] ),  act = SiLU if silu != 0
  * x, y: bf16 [M, C] (ldx, ldy); gamma fp32 [C]; beta fp32 [C] or NULL. fp32 statistics. C % 8 == 0, C <= 4096.
+ * y may be x (in place: every kernel form reads a row whole before it writes it). SiLU is x * rcp(1 + exp2(-x log2 e)) in the r6 forms
+ * (1 ulp of fp32, below the bf16 rounding of y).
  */
 int yume_vae_rmsnorm_silu(const void* x, int64_t ldx, int64_t M, int64_t C, const float* gamma, const float* beta,
                           int silu, void* y, int64_t ldy, void* stream);
