@@ -288,7 +288,9 @@ int yume_transpose_bf16(const void* in, int in_bf16, int64_t ldi, int64_t rows, 
  * Kernel choice (r3, inside the call; every path computes the same sum in fp32, in its own order): stride-1 convolutions whose frames
  *   are whole 256-position tiles with Cin % 64 == 0 (plain or with the folded upsample) run on the one-wave-per-SIMD pipeline
  *   (csrc/conv_w4.hpp; env YUME_CONV_W4=0: the 8-wave kernel); a causal 3x3x3 conv with Cout <= 16 on frames of >= 64 Ki positions
- *   (the decoder head) on the halo-tile kernel (csrc/conv_halo.hpp; YUME_CONV_HALO=0); everything else on the GEMM kernels with a
+ *   (the decoder head) on the halo-tile kernel (csrc/conv_halo.hpp; YUME_CONV_HALO=0); the 3x3 (x3) stride-1 convolutions of the 96 / 160-channel
+ *   levels on csrc/conv_halo_n.hpp (r6; YUME_CONV_HALO_N=0); the encoders' first convolution (8 -> 96, 16 -> 160 channels) on csrc/conv_in.hpp
+ *   (r6: weights resident in registers; YUME_CONV_IN=0); everything else on the GEMM kernels with a
  *   gathering A loader. YUME_CONV_KORDER=0/1/2 selects the K walk of that loader (default 2: dt, channel tile, dh, dw).
  * epi: YUME_EPI_BF16 (bias), YUME_EPI_F32, YUME_CONV_EPI_ADD (out = acc + bias + add[m, co], add bf16 [M, ldadd] —
  *      the ResidualBlock skip, vae2_2.py:239), YUME_CONV_EPI_TSPLIT (upsample3d time_conv, vae2_2.py:145-153:

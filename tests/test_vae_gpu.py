@@ -533,6 +533,41 @@ def test_conv_with_rms_norm_and_silu_behind_it(Cin, Cout, T, H, W):
     assert torch.equal(out, out2)
 
 
+@pytest.mark.parametrize("Creal,Cin,Cout,T,H,W,with_cache", [(3, 8, 96, 3, 136, 128, True), (3, 8, 96, 2, 130, 150, False), (12, 16, 160, 2, 132, 130, True),
+                                                             (12, 16, 160, 1, 128, 128, False)])
+def test_conv_in_first_convolution_of_the_encoders_vs_torch(Creal, Cin, Cout, T, H, W, with_cache):
+    """conv_in_kernel (r6): the encoders' first convolution — CausalConv3d(3, 96, 3, padding=1) of wan/modules/vae.py:291 on the 8-channel row
+    of the channels-last image, CausalConv3d(12, 160, 3, padding=1) of wan23/modules/vae2_2.py:525 on the 16-channel row — weights resident in
+    registers, halo tile in LDS. Whole and ragged tiles, with the causal cache and without it, every border face; the padding channels of the
+    input rows carry junk weights' worth of zeros (their weights are zero) and the launch repeated gives the same bits."""
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    x = torch.zeros(Cin, T, H, W)
+    x[:Creal] = rnd(Creal, T, H, W, seed=81).bfloat16().float()
+    cache = None
+    if with_cache:
+        cache = torch.zeros(Cin, 2, H, W)
+        cache[:Creal] = rnd(Creal, 2, H, W, seed=82).bfloat16().float()
+    w = torch.zeros(Cout, Cin, 3, 3, 3)
+    w[:, :Creal] = (rnd(Cout, Creal, 3, 3, 3, seed=83) * (27 * Creal) ** -0.5).bfloat16().float()
+    b = rnd(Cout, seed=84) * 0.1
+    xin = torch.cat([cache, x], dim=1) if with_cache else F.pad(x, (0, 0, 0, 0, 2, 0))
+    want = F.conv3d(F.pad(xin.unsqueeze(0), (1, 1, 1, 1)), w, b)[0]
+    out = torch.full((T, H, W, Cout), 7.0, dtype=torch.bfloat16, device=DEV)
+    V.conv3d_cl(cl(x), cl(cache) if with_cache else None, pack_w(w), b.to(DEV), Cout, (3, 3, 3), (1, 1, 1), (2, 1, 1), False, out,
+                V.EPI_BF16, zero_page=zero_page())
+    got = ncthw(out)
+    assert torch.isfinite(got).all()
+    assert rel_l2(got, want) < 5e-3, rel_l2(got, want)
+    assert (got - want).abs().max() <= 2.0 ** -6 * want.abs().max() + 1e-3
+    for sl in ((slice(None), 0), (slice(None), -1), (slice(None), slice(None), 0), (slice(None), slice(None), -1),
+               (slice(None), slice(None), slice(None), 0), (slice(None), slice(None), slice(None), -1)):
+        assert rel_l2(got[sl], want[sl]) < 5e-3, sl
+    out2 = torch.empty_like(out)
+    V.conv3d_cl(cl(x), cl(cache) if with_cache else None, pack_w(w), b.to(DEV), Cout, (3, 3, 3), (1, 1, 1), (2, 1, 1), False, out2,
+                V.EPI_BF16, zero_page=zero_page())
+    assert torch.equal(out, out2)
+
+
 @pytest.mark.parametrize("with_cache,H,W", [(True, 136, 128), (False, 130, 150)])
 def test_conv_halo_n_head_96_to_4_channels_vs_torch(with_cache, H, W):
     """the Wan2.1 decoder's head (wan/modules/vae.py:466-468: RMS_norm, SiLU, CausalConv3d(96, 3, 3, padding=1)) — 4 (3 + pad) output channels in

@@ -15,6 +15,7 @@
 #include "conv_w4.hpp"
 #include "conv_halo.hpp"
 #include "conv_halo_n.hpp"
+#include "conv_in.hpp"
 
 using namespace gemm_core;
 
@@ -253,6 +254,31 @@ extern "C" int yume_conv3d_cl(const void* x, const void* cache, int64_t ldc, int
     e.hw = (int)(Ho * Wo);
     hipStream_t s = (hipStream_t)stream;
     const bool big = use_256(p, variant, true);
+    if (conv_in::applies(Cin, Cout, kt, kh, kw, st, sh, sw, pt, ph, pw, ups, Hin, Win, Ho, Wo, ldc, ldo, ldw, epi)) {
+        // the encoders' first convolution (8 -> 96, 16 -> 160 channels): weights resident in registers, halo tile in LDS (conv_in.hpp)
+        conv_in::Params ip;
+        ip.x = al.x; ip.cache = al.cache; ip.w = (const unsigned short*)W; ip.bias = bias; ip.out = (unsigned short*)out;
+        ip.ldw = ldw; ip.ldo = ldo;
+        ip.Tin = (int)Tin; ip.H = (int)Hin; ip.W = (int)Win; ip.To = (int)To; ip.cout = (int)Cout;
+        static const bool log_on = [] { const char* v = getenv("YUME_CONV_LOG"); return v && atoi(v) != 0; }();
+        if (log_on) fprintf(stderr, "[conv3d_cl] conv_in M=%lld Cin=%lld Cout=%lld k=%dx%dx%d\n", (long long)M, (long long)Cin, (long long)Cout, kt, kh, kw);
+        int rc = 0;
+        if (Cin == 8) {
+            rc = conv_in::launch<8, 6>(ip, To, Ho, Wo, s);
+        } else {
+            for (int ch = 0; ch < 2 && rc == 0; ++ch) {          // 160 output channels = two launches of 80 (280 weight registers per lane each)
+                conv_in::Params q = ip;
+                q.w = ip.w + (int64_t)ch * 80 * ldw;
+                q.bias = bias ? bias + ch * 80 : nullptr;
+                q.out = ip.out + ch * 80;
+                q.cout = 80;
+                rc = conv_in::launch<16, 5>(q, To, Ho, Wo, s);
+            }
+        }
+        YUME_REQUIRE(rc == 0, "conv3d_cl: too many tiles");
+        YUME_CHECK_LAUNCH("conv3d_cl");
+        return YUME_OK;
+    }
     if (conv_halo::applies(Cin, Cout, kt, kh, kw, st, sh, sw, pt, ph, pw, ups, Hin, Win, Ho, Wo, ldc, ldo, ldw, epi)) {
         // few output channels at full resolution (the decoder's head): halo tile in LDS, the 9 in-plane taps out of it (conv_halo.hpp)
         conv_halo::Params hp;
