@@ -162,6 +162,9 @@ struct Blk {             // the compiler-managed part of a block (O^T and Q^T ar
 template <int I, bool MASK, bool FAST>
 __device__ __forceinline__ void sm_piece(Soft& z, const f32x16 (&s)[2], u32x4 (&pf)[4], float c, int keyb, int Lk) {
     auto row_sum = [&]() {
+#if A7_DOT2_ROWSUM
+        if constexpr (FAST) return;            // (experiment: the pack pieces sum the bf16 pairs they have just made, v_dot2c_f32_bf16)
+#endif
         if constexpr (I >= 2 && I <= 33) {
             constexpr int e = I - 2;
             if constexpr (e == 0) z.sum0 = z.p[0];
@@ -182,6 +185,21 @@ __device__ __forceinline__ void sm_piece(Soft& z, const f32x16 (&s)[2], u32x4 (&
                 z.w1 = z.od;
                 pf[g][k] = z.ev;
                 pf[g][2 + k] = z.od;
+#if A7_DOT2_ROWSUM
+                if constexpr (FAST) {
+                    // row sum on the dot unit: the two bf16 pairs just packed times (1, 1) — 4 issues per 8 exponentials instead of 8 adds; the sum is
+                    // then the sum of the ROUNDED exponentials (the ones the P.V product uses), not of the fp32 ones the reference sums
+                    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+                    const bf16x2_t one2 = __builtin_bit_cast(bf16x2_t, 0x3f803f80u);
+                    if constexpr (g == 0 && k == 0) {
+                        z.sum0 = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, z.ev), one2, 0.f, false);
+                        z.sum1 = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, z.od), one2, 0.f, false);
+                    } else {
+                        z.sum0 = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, z.ev), one2, z.sum0, false);
+                        z.sum1 = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, z.od), one2, z.sum1, false);
+                    }
+                }
+#endif
             }
 #else
             if constexpr (k == 1 || k == 2) {          // swap of pair k - 1
@@ -364,6 +382,10 @@ __device__ __forceinline__ void fix7_v(const Dma7& d, const AttnArgs& p, int t, 
 #endif
 // timing ablations of the steady tile's meeting point (WRONG results; profiles/r6_attention_steady_barrier_ablation.log): which of the
 // counted wait and the barrier the waves are parked at
+// experiment (second candidate): the row sums of the base-free body on v_dot2_f32_bf16 (profiles/r6_attention_dot2_rowsum.log)
+#ifndef A7_DOT2_ROWSUM
+#define A7_DOT2_ROWSUM 0
+#endif
 #ifndef ATTN_ABLATE_STEADY_BAR
 #define ATTN_ABLATE_STEADY_BAR 0
 #endif
